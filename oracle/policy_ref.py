@@ -1,0 +1,115 @@
+"""Oracle: policy networks + action distributions (plain torch CPU ops).
+
+TEST INFRASTRUCTURE -- see oracle/__init__.py.
+
+Parameters are an ordered dict ``name -> tensor`` using the reference's
+``state_dict`` names so a reference ``Policy.state_dict()`` drops straight in:
+
+NatureCNN + Categorical (reference model.py:169-195, distributions.py:59-73)
+    base.main.{0,2,4}.{weight,bias}  conv 8x8s4 / 4x4s2 / 3x3s1, 32-64-32 ch
+    base.main.7.{weight,bias}        Linear(32*7*7 -> hidden)
+    base.critic_linear.{weight,bias} Linear(hidden -> 1)
+    dist.linear.{weight,bias}        Linear(hidden -> A)
+MLPBase + DiagGaussian (model.py:198-229, distributions.py:76-95)
+    base.actor.{0,2}.*, base.critic.{0,2}.*, base.critic_linear.*,
+    dist.fc_mean.*, dist.logstd._bias [A,1]
+"""
+import math
+from collections import OrderedDict
+
+import torch
+import torch.nn.functional as F
+
+
+def cnn_param_shapes(num_inputs=4, hidden=512, num_actions=6):
+    """Order == reference ``Policy.parameters()`` order (model.py:176-185)."""
+    return OrderedDict([
+        ('base.main.0.weight', (32, num_inputs, 8, 8)), ('base.main.0.bias', (32,)),
+        ('base.main.2.weight', (64, 32, 4, 4)), ('base.main.2.bias', (64,)),
+        ('base.main.4.weight', (32, 64, 3, 3)), ('base.main.4.bias', (32,)),
+        ('base.main.7.weight', (hidden, 32 * 7 * 7)), ('base.main.7.bias', (hidden,)),
+        ('base.critic_linear.weight', (1, hidden)), ('base.critic_linear.bias', (1,)),
+        ('dist.linear.weight', (num_actions, hidden)), ('dist.linear.bias', (num_actions,)),
+    ])
+
+
+def mlp_param_shapes(num_inputs, hidden=64, num_actions=3):
+    """Order == reference ``Policy.parameters()`` order (model.py:208-216)."""
+    return OrderedDict([
+        ('base.actor.0.weight', (hidden, num_inputs)), ('base.actor.0.bias', (hidden,)),
+        ('base.actor.2.weight', (hidden, hidden)), ('base.actor.2.bias', (hidden,)),
+        ('base.critic.0.weight', (hidden, num_inputs)), ('base.critic.0.bias', (hidden,)),
+        ('base.critic.2.weight', (hidden, hidden)), ('base.critic.2.bias', (hidden,)),
+        ('base.critic_linear.weight', (1, hidden)), ('base.critic_linear.bias', (1,)),
+        ('dist.fc_mean.weight', (num_actions, hidden)), ('dist.fc_mean.bias', (num_actions,)),
+        ('dist.logstd._bias', (num_actions, 1)),
+    ])
+
+
+def is_cnn(P):
+    return 'base.main.0.weight' in P
+
+
+def cnn_base(P, obs):
+    """model.py:189-195 (non-recurrent): returns (value [B,1], features [B,hidden])."""
+    x = obs / 255.0
+    x = F.relu(F.conv2d(x, P['base.main.0.weight'], P['base.main.0.bias'], stride=4))
+    x = F.relu(F.conv2d(x, P['base.main.2.weight'], P['base.main.2.bias'], stride=2))
+    x = F.relu(F.conv2d(x, P['base.main.4.weight'], P['base.main.4.bias'], stride=1))
+    x = x.reshape(x.size(0), -1)
+    x = F.relu(F.linear(x, P['base.main.7.weight'], P['base.main.7.bias']))
+    value = F.linear(x, P['base.critic_linear.weight'], P['base.critic_linear.bias'])
+    return value, x
+
+
+def mlp_base(P, obs):
+    """model.py:220-229 (non-recurrent): separate tanh towers."""
+    hc = torch.tanh(F.linear(obs, P['base.critic.0.weight'], P['base.critic.0.bias']))
+    hc = torch.tanh(F.linear(hc, P['base.critic.2.weight'], P['base.critic.2.bias']))
+    ha = torch.tanh(F.linear(obs, P['base.actor.0.weight'], P['base.actor.0.bias']))
+    ha = torch.tanh(F.linear(ha, P['base.actor.2.weight'], P['base.actor.2.bias']))
+    value = F.linear(hc, P['base.critic_linear.weight'], P['base.critic_linear.bias'])
+    return value, ha
+
+
+def categorical_logp_entropy(logits_raw, actions):
+    """distributions.py:18-29 over torch/distributions/categorical.py:78,150-162.
+
+    logits -= logsumexp; log_prob = gather; entropy = -sum(clamp(logits)*softmax).
+    Returns (log_probs [B,1], entropy [B]).
+    """
+    logits = logits_raw - logits_raw.logsumexp(dim=-1, keepdim=True)
+    probs = F.softmax(logits, dim=-1)
+    logp = logits.gather(-1, actions.long().view(-1, 1))
+    min_real = torch.finfo(logits.dtype).min
+    ent = -(torch.clamp(logits, min=min_real) * probs).sum(-1)
+    return logp, ent
+
+
+def normal_logp_entropy(mean, logstd_bias, actions):
+    """distributions.py:36-41,86-95 over torch/distributions/normal.py:88-103,115-116.
+
+    logstd = zeros + bias.t(); std = exp(logstd);
+    log_prob = -(a-mu)^2/(2 var) - log(std) - log(sqrt(2 pi)), summed over A (keepdim);
+    entropy = sum_A (0.5 + 0.5 log(2 pi) + log(std)).
+    """
+    logstd = torch.zeros_like(mean) + logstd_bias.t().view(1, -1)
+    std = logstd.exp()
+    var = std ** 2
+    log_scale = std.log()
+    lp = -((actions - mean) ** 2) / (2 * var) - log_scale - math.log(math.sqrt(2 * math.pi))
+    ent = 0.5 + 0.5 * math.log(2 * math.pi) + torch.log(std)
+    return lp.sum(-1, keepdim=True), ent.sum(-1)
+
+
+def evaluate_actions(P, obs, actions):
+    """model.py:72-79: (value [B,1], action_log_probs [B,1], entropy.mean() scalar)."""
+    if is_cnn(P):
+        value, feat = cnn_base(P, obs)
+        logits = F.linear(feat, P['dist.linear.weight'], P['dist.linear.bias'])
+        logp, ent = categorical_logp_entropy(logits, actions)
+    else:
+        value, feat = mlp_base(P, obs)
+        mean = F.linear(feat, P['dist.fc_mean.weight'], P['dist.fc_mean.bias'])
+        logp, ent = normal_logp_entropy(mean, P['dist.logstd._bias'], actions)
+    return value, logp, ent.mean()

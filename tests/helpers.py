@@ -1,0 +1,72 @@
+"""Shared helpers for parity tests (golden loading, summaries, tolerances)."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+SAMPLE_STRIDE = 101
+
+
+def golden(name):
+    return np.load(os.path.join(GOLD, name + '.npz'), allow_pickle=False)
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def params_torch(P):
+    return OrderedDict((k, t(v).clone()) for k, v in P.items())
+
+
+def rel_err(a, b):
+    a = np.asarray(a, np.float64).reshape(-1)
+    b = np.asarray(b, np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+def check_summary(G, prefix, arr, tol, what=''):
+    """Compare a tensor with the golden's (norm, full|sample) summary; relative L2 metric."""
+    a = np.asarray(arr, np.float32).reshape(-1)
+    gn = float(G[prefix + '#norm'])
+    n = float(np.sqrt((a.astype(np.float64) ** 2).sum()))
+    assert abs(n - gn) <= tol * max(gn, 1e-12) + 1e-12, '%s %s norm %g vs %g' % (what, prefix, n, gn)
+    if prefix + '#full' in G.files:
+        ref = G[prefix + '#full']
+        got = a
+    else:
+        ref = G[prefix + '#sample']
+        got = a[::SAMPLE_STRIDE]
+    scale = max(gn / np.sqrt(a.size), 1e-30) * np.sqrt(ref.size)   # expected norm of the compared subset
+    err = float(np.linalg.norm(got.astype(np.float64) - ref.astype(np.float64)))
+    assert err <= tol * max(scale, float(np.linalg.norm(ref))) + 1e-12, \
+        '%s %s rel err %g' % (what, prefix, err / max(scale, 1e-30))
+
+
+def eval_case_inputs(tag, kind, od, A, B, ci):
+    """Inputs of golden group 'eval' (mirrors tests/golden/make_golden.py:g_eval)."""
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    ro = synth.make_rollouts(1, B, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=900 + ci)
+    return dict(obs=ro['obs'][0], act=ro['actions'][0], vp=ro['value_preds'][0],
+                ret=synth.normalish((B, 1), 950 + ci), adv=synth.normalish((B, 1), 960 + ci))
+
+
+EVAL_CASES = [('mlp11', 'mlp', 11, 3, 64, 0.2, 0.0), ('mlp17', 'mlp', 17, 6, 64, 0.2, 0.01),
+              ('cnn16', 'cnn', None, 6, 16, 0.1, 0.01), ('cnn80', 'cnn', None, 6, 80, 0.1, 0.01)]
+
+PPO_CASES = [('mlp', 'mlp', 11, 3, 32, 4, dict(clip_param=0.2, ppo_epoch=3, num_mini_batch=4, value_loss_coef=0.5,
+                                               entropy_coef=0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)),
+             ('cnn', 'cnn', None, 6, 8, 4, dict(clip_param=0.1, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5,
+                                                entropy_coef=0.01, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5))]
+
+A2C_HP = dict(value_loss_coef=0.5, entropy_coef=0.01, lr=7e-4, eps=1e-5, alpha=0.99, max_grad_norm=0.5)
+A2C_CASES = [('cnn', 'cnn', None, 6, 5, 16), ('mlp', 'mlp', 17, 6, 5, 16)]
+
+
+def shapes_for(kind, od, A):
+    from oracle import policy_ref
+    return policy_ref.cnn_param_shapes(4, 512, A) if kind == 'cnn' else policy_ref.mlp_param_shapes(od, 64, A)

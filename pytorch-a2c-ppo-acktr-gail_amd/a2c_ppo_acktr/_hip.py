@@ -1,0 +1,82 @@
+"""ctypes binding of libacktr_hip.so (the C-ABI declared in include/acktr_hip.h).
+
+PyTorch is only plumbing here: device memory (``tensor.data_ptr()``) and the
+current HIP stream.  There is NO fallback: if the library is missing or a
+tensor is not on the GPU the call raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libacktr_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+
+c_p = ctypes.c_void_p
+c_i = ctypes.c_int
+c_l = ctypes.c_long
+c_f = ctypes.c_float
+
+# name -> (restype, argtypes); mirrors include/acktr_hip.h one to one
+_PROTOS = {
+    'acktr_abi_version': (c_i, []),
+    'acktr_target_arch': (ctypes.c_char_p, []),
+    'acktr_last_error': (ctypes.c_char_p, []),
+    'acktr_compute_returns_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_f, c_i, c_i, c_p]),
+    'acktr_adv_normalize_workspace_bytes': (c_l, []),
+    'acktr_adv_normalize_f32': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p]),
+    'acktr_gather_rows': (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
+}
+
+
+def register(name, restype, argtypes):
+    """Used by sibling modules to declare further entry points of the same library."""
+    _PROTOS[name] = (restype, argtypes)
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.restype, fn.argtypes = restype, argtypes
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libacktr_hip.so not found at %s -- build it with '
+                '`python pytorch-a2c-ppo-acktr-gail_amd/csrc/build.py` (hipcc, gfx950). '
+                'There is no CPU fallback for this package.' % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(_lib, name)          # AttributeError if the .so lacks a declared symbol
+            fn.restype, fn.argtypes = res, args
+        v = _lib.acktr_abi_version()
+        if v != ABI_VERSION:
+            raise RuntimeError('libacktr_hip.so ABI %d != expected %d (stale build?)' % (v, ABI_VERSION))
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().acktr_last_error().decode('utf-8', 'replace')
+        raise RuntimeError('%s failed (rc=%d): %s' % (what, rc, msg))
+
+
+def dev_ptr(t, dtype=None, name='tensor'):
+    """Device pointer of a contiguous GPU tensor; raises for anything else (no silent copies)."""
+    if t is None:
+        return c_p(None)
+    if not t.is_cuda:
+        raise RuntimeError('%s must live on the MI355X device (got %s): this package has no CPU path'
+                           % (name, t.device))
+    if not t.is_contiguous():
+        raise RuntimeError('%s must be contiguous' % name)
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError('%s must be %s (got %s)' % (name, dtype, t.dtype))
+    return c_p(t.data_ptr())
+
+
+def cur_stream(device=None):
+    return c_p(torch.cuda.current_stream(device).cuda_stream)

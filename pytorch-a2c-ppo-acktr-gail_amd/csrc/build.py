@@ -1,0 +1,69 @@
+"""Build libacktr_hip.so (gfx950) in-tree with hipcc.  Called by __graft_entry__.build().
+
+    python pytorch-a2c-ppo-acktr-gail_amd/csrc/build.py [--force] [-j N]
+
+Each .hip file is compiled to an object (cached on mtime of the source + headers) and the
+objects are linked into ../lib/libacktr_hip.so.  Cross-compiles without a GPU.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+OBJ = os.path.join(HERE, 'build')
+LIBDIR = os.path.join(os.path.dirname(HERE), 'lib')
+LIB = os.path.join(LIBDIR, 'libacktr_hip.so')
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+         '-I', os.path.join(ROOT, 'include'), '-I', HERE, '-I', '/opt/rocm/include']
+LINK = ['-L/opt/rocm/lib', '-lrocsolver', '-lrocblas', '-Wl,-rpath,/opt/rocm/lib']
+
+
+def _newest_header():
+    hs = [os.path.join(HERE, f) for f in os.listdir(HERE) if f.endswith(('.hpp', '.h'))]
+    hs.append(os.path.join(ROOT, 'include', 'acktr_hip.h'))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def build(force=False, jobs=None):
+    os.makedirs(OBJ, exist_ok=True)
+    os.makedirs(LIBDIR, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(HERE) if f.endswith('.hip'))
+    hdr_t = _newest_header()
+    todo, objs = [], []
+    for s in srcs:
+        src = os.path.join(HERE, s)
+        obj = os.path.join(OBJ, s[:-4] + '.o')
+        objs.append(obj)
+        if force or not os.path.exists(obj) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+            todo.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC] + FLAGS + ['-c', src, '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, r.stdout, r.stderr))
+        if r.stderr.strip():
+            sys.stderr.write(r.stderr)
+        return obj
+
+    if todo:
+        jobs = jobs or min(8, len(todo))
+        with ThreadPoolExecutor(max_workers=jobs) as ex:
+            list(ex.map(cc, todo))
+    if todo or not os.path.exists(LIB):
+        cmd = [HIPCC, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + LINK
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (r.stdout, r.stderr))
+    return LIB
+
+
+if __name__ == '__main__':
+    j = None
+    if '-j' in sys.argv:
+        j = int(sys.argv[sys.argv.index('-j') + 1])
+    print(build(force='--force' in sys.argv, jobs=j))

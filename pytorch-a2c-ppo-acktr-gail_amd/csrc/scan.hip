@@ -1,0 +1,265 @@
+// Return / GAE reverse scan, advantage normalisation, minibatch row gather.
+//
+// compute_returns restates a2c_ppo_acktr/storage.py:66-105 of the reference:
+// a serial-in-t recurrence per environment whose fp32 association must be kept
+// (bit-exact contract), so time cannot be parallelised.  Design for MI355X:
+//   * one lane per environment, 32 environments per workgroup (128-B rows);
+//   * all 4 waves of the workgroup prefetch the NEXT 64-step chunk straight to
+//     registers and pre-compute everything that does not depend on the carried
+//     value (delta, gamma*lambda*mask, (1-bad)*V) -> LDS, double buffered;
+//   * wave 0 runs the dependent chain (2-5 flops/step) out of LDS and streams
+//     the returns rows back with coalesced stores.
+// The chain latency (T x ~20 cycles) is the floor; HBM traffic is the
+// algorithmic minimum (every input element read once, every output written once).
+//
+// No FMA contraction anywhere in this file: products and sums are rounded
+// separately, exactly as the reference's separate torch ops do.
+#include "common.hpp"
+#include "../../include/acktr_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace acktr {
+
+constexpr int SCAN_TE = 32;   // environments per workgroup
+constexpr int SCAN_TC = 64;   // time steps per chunk
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_EPT = SCAN_TE * SCAN_TC / SCAN_THREADS;   // elements per thread per chunk (8)
+
+template <bool GAE, bool PROPER>
+__global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
+    const float* rewards, float* value_preds, float* returns, const float* masks, const float* bad_masks,
+    const float* next_value, int T, int N, float g, float gl) {
+    constexpr int NARR = PROPER ? 4 : (GAE ? 3 : 2);
+    __shared__ float lds[2][NARR][SCAN_TC][SCAN_TE];
+
+    const int tid = threadIdx.x;
+    const int e0 = blockIdx.x * SCAN_TE;
+    const int nchunks = (T + SCAN_TC - 1) / SCAN_TC;
+
+    // side effect of the reference: value_preds[-1] = next_value (GAE) / returns[-1] = next_value
+    if (tid < SCAN_TE && e0 + tid < N) {
+        const float nv = next_value[e0 + tid];
+        if (GAE) value_preds[(long)T * N + e0 + tid] = nv;
+        else returns[(long)T * N + e0 + tid] = nv;
+    }
+
+    float st[SCAN_EPT][5];
+
+    auto issue_loads = [&](int c) {
+        const int tlo = T - (c + 1) * SCAN_TC;
+#pragma unroll
+        for (int i = 0; i < SCAN_EPT; ++i) {
+            const int e = tid + SCAN_THREADS * i;
+            const int j = e / SCAN_TE, le = e % SCAN_TE;
+            const int t = tlo + j, n = e0 + le;
+            const bool ok = (t >= 0) && (n < N);
+            const long o = (long)t * N + n;
+            st[i][0] = ok ? rewards[o] : 0.f;
+            st[i][1] = ok ? masks[o + N] : 0.f;                       // masks[t+1]
+            if (GAE || PROPER) st[i][2] = ok ? value_preds[o] : 0.f;  // V[t]
+            if (GAE) st[i][3] = ok ? ((t == T - 1) ? next_value[n] : value_preds[o + N]) : 0.f;   // V[t+1]
+            if (PROPER) st[i][4] = ok ? bad_masks[o + N] : 0.f;       // bad_masks[t+1]
+        }
+    };
+    auto stage_to_lds = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < SCAN_EPT; ++i) {
+            const int e = tid + SCAN_THREADS * i;
+            const int j = e / SCAN_TE, le = e % SCAN_TE;
+            const float r = st[i][0], m = st[i][1];
+            if (GAE) {
+                // delta = (r + (g*V[t+1])*m) - V[t]          storage.py:77-79 / 95-97
+                const float delta = __fsub_rn(__fadd_rn(r, __fmul_rn(__fmul_rn(g, st[i][3]), m)), st[i][2]);
+                lds[buf][0][j][le] = delta;
+                lds[buf][1][j][le] = __fmul_rn(gl, m);                 // (gamma*lambda)*mask
+                lds[buf][2][j][le] = st[i][2];
+                if (PROPER) lds[buf][3][j][le] = st[i][4];
+            } else {
+                lds[buf][0][j][le] = m;
+                lds[buf][1][j][le] = r;
+                if (PROPER) {
+                    lds[buf][2][j][le] = st[i][4];
+                    lds[buf][3][j][le] = __fmul_rn(__fsub_rn(1.0f, st[i][4]), st[i][2]);   // (1-b)*V[t]
+                }
+            }
+        }
+    };
+
+    issue_loads(0);
+    stage_to_lds(0);
+    __syncthreads();
+
+    float carry = 0.f;   // gae (GAE) or returns[t+1] (RET)
+    if (!GAE && tid < SCAN_TE && e0 + tid < N) carry = next_value[e0 + tid];
+
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) issue_loads(c + 1);      // in flight during the serial scan below
+
+        if (tid < SCAN_TE) {                          // wave 0, lanes 0..31: the dependent chain
+            const int n = e0 + tid;
+            const int tlo = T - (c + 1) * SCAN_TC;
+            float* out = returns + (long)tlo * N + n;
+#pragma unroll 8
+            for (int j = SCAN_TC - 1; j >= 0; --j) {
+                const float x0 = lds[buf][0][j][tid];
+                const float x1 = lds[buf][1][j][tid];
+                float res;
+                if (GAE) {
+                    carry = __fadd_rn(x0, __fmul_rn(x1, carry));                 // gae = delta + (gl*m)*gae
+                    if (PROPER) carry = __fmul_rn(carry, lds[buf][3][j][tid]);   // gae *= bad_mask
+                    res = __fadd_rn(carry, lds[buf][2][j][tid]);                 // R = gae + V[t]
+                } else {
+                    carry = __fadd_rn(__fmul_rn(__fmul_rn(carry, g), x0), x1);   // (R*g)*m + r
+                    if (PROPER)
+                        carry = __fadd_rn(__fmul_rn(carry, lds[buf][2][j][tid]), lds[buf][3][j][tid]);
+                    res = carry;
+                }
+                if (tlo + j >= 0 && n < N) out[(long)j * N] = res;
+            }
+        }
+        if (c + 1 < nchunks) stage_to_lds(buf ^ 1);
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Advantage normalisation (ppo.py:35-37): adv = R - V; (adv - mean)/(std_unbiased + 1e-5)
+// pass 1: per-block fp64 partial (sum, sum of squares); pass 2: every block re-reduces the
+// partials in a fixed order (deterministic) and normalises its slice.
+// ---------------------------------------------------------------------------
+constexpr int ADV_THREADS = 256;
+constexpr int ADV_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(ADV_THREADS) void adv_partial_kernel(const float* returns, const float* value_preds,
+                                                                 long n, double* partial) {
+    __shared__ double sm[16];
+    double s = 0.0, s2 = 0.0;
+    for (long i = (long)blockIdx.x * ADV_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * ADV_THREADS) {
+        const float a = __fsub_rn(returns[i], value_preds[i]);
+        s += (double)a;
+        s2 += (double)a * (double)a;
+    }
+    s = block_sum(s, sm);
+    s2 = block_sum(s2, sm);
+    if (threadIdx.x == 0) {
+        partial[2 * blockIdx.x] = s;
+        partial[2 * blockIdx.x + 1] = s2;
+    }
+}
+
+__global__ __launch_bounds__(ADV_THREADS) void adv_normalize_kernel(const float* returns, const float* value_preds,
+                                                                   float* adv, long n, const double* partial,
+                                                                   int nparts) {
+    __shared__ float ms[2];
+    if (threadIdx.x < 64) {
+        double s = 0.0, s2 = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 64) {
+            s += partial[2 * i];
+            s2 += partial[2 * i + 1];
+        }
+        s = wave_sum(s);
+        s2 = wave_sum(s2);
+        if (threadIdx.x == 0) {
+            const double mean = s / (double)n;
+            double var = (s2 - s * mean) / (double)(n - 1);   // unbiased
+            if (var < 0.0) var = 0.0;
+            ms[0] = (float)mean;
+            ms[1] = (float)sqrt(var);
+        }
+    }
+    __syncthreads();
+    const float mean = ms[0];
+    const float denom = __fadd_rn(ms[1], 1e-5f);
+    for (long i = (long)blockIdx.x * ADV_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * ADV_THREADS) {
+        const float a = __fsub_rn(returns[i], value_preds[i]);
+        adv[i] = __fdiv_rn(__fsub_rn(a, mean), denom);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row gather (storage.py:127-140): dst[i, :] = src[idx[i], :]
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const T* src, const int64_t* idx, T* dst, long rows,
+                                                          long row_elems, long src_rows) {
+    const long row = blockIdx.x;
+    const long s = idx[row];
+    if (s < 0 || s >= src_rows) return;   // host validates; never fault
+    const T* sp = src + s * row_elems;
+    T* dp = dst + row * row_elems;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < row_elems; i += (long)gridDim.y * 256) dp[i] = sp[i];
+}
+
+}  // namespace acktr
+
+using namespace acktr;
+
+extern "C" int acktr_compute_returns_f32(const float* rewards, float* value_preds, float* returns,
+                                         const float* masks, const float* bad_masks, const float* next_value,
+                                         int T, int N, float gamma32, float gamma_lambda32, int use_gae,
+                                         int use_proper_time_limits, void* stream) {
+    ACKTR_ARG(rewards && value_preds && returns && masks && next_value, "compute_returns: null pointer");
+    ACKTR_ARG(!use_proper_time_limits || bad_masks, "compute_returns: bad_masks required");
+    ACKTR_ARG(T > 0 && N > 0, "compute_returns: T=%d N=%d must be positive", T, N);
+    ACKTR_ARG((long)(T + 1) * N < (1L << 31), "compute_returns: (T+1)*N too large");
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(cdiv(N, SCAN_TE)), block(SCAN_THREADS);
+#define LAUNCH(G, P)                                                                                          \
+    hipLaunchKernelGGL((returns_scan_kernel<G, P>), grid, block, 0, s, rewards, value_preds, returns, masks, \
+                       bad_masks, next_value, T, N, gamma32, gamma_lambda32)
+    if (use_gae) {
+        if (use_proper_time_limits) LAUNCH(true, true); else LAUNCH(true, false);
+    } else {
+        if (use_proper_time_limits) LAUNCH(false, true); else LAUNCH(false, false);
+    }
+#undef LAUNCH
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" long acktr_adv_normalize_workspace_bytes(void) { return (long)ADV_MAX_BLOCKS * 2 * sizeof(double); }
+
+extern "C" int acktr_adv_normalize_f32(const float* returns, const float* value_preds, float* adv, long n,
+                                       void* workspace, void* stream) {
+    ACKTR_ARG(returns && value_preds && adv && workspace, "adv_normalize: null pointer");
+    ACKTR_ARG(n >= 2, "adv_normalize: need n >= 2 for the unbiased std (n=%ld)", n);
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = cdiv(n, ADV_THREADS * 8);
+    if (blocks > ADV_MAX_BLOCKS) blocks = ADV_MAX_BLOCKS;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(adv_partial_kernel, dim3(blocks), dim3(ADV_THREADS), 0, s, returns, value_preds, n,
+                       (double*)workspace);
+    ACKTR_LAUNCH_CHECK();
+    int nblocks2 = cdiv(n, ADV_THREADS * 4);
+    if (nblocks2 > 2048) nblocks2 = 2048;
+    hipLaunchKernelGGL(adv_normalize_kernel, dim3(nblocks2), dim3(ADV_THREADS), 0, s, returns, value_preds, adv, n,
+                       (const double*)workspace, blocks);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_gather_rows(const void* src, const int64_t* idx, void* dst, long rows, long row_bytes,
+                                 long src_rows, void* stream) {
+    ACKTR_ARG(src && idx && dst, "gather_rows: null pointer");
+    ACKTR_ARG(rows >= 0 && row_bytes > 0 && src_rows > 0, "gather_rows: bad sizes");
+    if (rows == 0) return 0;
+    ACKTR_ARG(rows < (1L << 31), "gather_rows: too many rows");
+    hipStream_t s = (hipStream_t)stream;
+    const bool v16 = (row_bytes % 16 == 0) && (((uintptr_t)src | (uintptr_t)dst) % 16 == 0);
+    if (v16) {
+        const long ne = row_bytes / 16;
+        int bx = cdiv(ne, 256 * 4); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+        hipLaunchKernelGGL((gather_rows_kernel<float4>), dim3((unsigned)rows, bx), dim3(256), 0, s,
+                           (const float4*)src, idx, (float4*)dst, rows, ne, src_rows);
+    } else {
+        ACKTR_ARG(row_bytes % 4 == 0, "gather_rows: row_bytes must be a multiple of 4");
+        const long ne = row_bytes / 4;
+        int bx = cdiv(ne, 256 * 4); if (bx < 1) bx = 1; if (bx > 64) bx = 64;
+        hipLaunchKernelGGL((gather_rows_kernel<float>), dim3((unsigned)rows, bx), dim3(256), 0, s,
+                           (const float*)src, idx, (float*)dst, rows, ne, src_rows);
+    }
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}

@@ -16,7 +16,7 @@ OBJ = os.path.join(HERE, 'build')
 LIBDIR = os.path.join(os.path.dirname(HERE), 'lib')
 LIB = os.path.join(LIBDIR, 'libacktr_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function',
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-I', os.path.join(ROOT, 'include'), '-I', HERE, '-I', '/opt/rocm/include']
 LINK = ['-L/opt/rocm/lib', '-lrocsolver', '-lrocblas', '-Wl,-rpath,/opt/rocm/lib']
 

@@ -12,8 +12,10 @@
 // The chain latency (T x ~20 cycles) is the floor; HBM traffic is the
 // algorithmic minimum (every input element read once, every output written once).
 //
-// No FMA contraction anywhere in this file: products and sums are rounded
-// separately, exactly as the reference's separate torch ops do.
+// No FMA contraction anywhere in this file (pragma below + -ffp-contract=off on the command line):
+// products and sums are rounded separately, exactly as the reference's separate torch ops do.
+// Plain operators are used on purpose: the __f*_rn() header wrappers are compiled under the
+// header's own contraction mode and DO fuse into v_fma after inlining.
 #include "common.hpp"
 #include "../../include/acktr_hip.h"
 
@@ -70,9 +72,9 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
             const float r = st[i][0], m = st[i][1];
             if (GAE) {
                 // delta = (r + (g*V[t+1])*m) - V[t]          storage.py:77-79 / 95-97
-                const float delta = __fsub_rn(__fadd_rn(r, __fmul_rn(__fmul_rn(g, st[i][3]), m)), st[i][2]);
+                const float delta = ((((r) + (((((g) * (st[i][3]))) * (m))))) - (st[i][2]));
                 lds[buf][0][j][le] = delta;
-                lds[buf][1][j][le] = __fmul_rn(gl, m);                 // (gamma*lambda)*mask
+                lds[buf][1][j][le] = ((gl) * (m));                 // (gamma*lambda)*mask
                 lds[buf][2][j][le] = st[i][2];
                 if (PROPER) lds[buf][3][j][le] = st[i][4];
             } else {
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
                 lds[buf][1][j][le] = r;
                 if (PROPER) {
                     lds[buf][2][j][le] = st[i][4];
-                    lds[buf][3][j][le] = __fmul_rn(__fsub_rn(1.0f, st[i][4]), st[i][2]);   // (1-b)*V[t]
+                    lds[buf][3][j][le] = ((((1.0f) - (st[i][4]))) * (st[i][2]));   // (1-b)*V[t]
                 }
             }
         }
@@ -107,13 +109,13 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
                 const float x1 = lds[buf][1][j][tid];
                 float res;
                 if (GAE) {
-                    carry = __fadd_rn(x0, __fmul_rn(x1, carry));                 // gae = delta + (gl*m)*gae
-                    if (PROPER) carry = __fmul_rn(carry, lds[buf][3][j][tid]);   // gae *= bad_mask
-                    res = __fadd_rn(carry, lds[buf][2][j][tid]);                 // R = gae + V[t]
+                    carry = ((x0) + (((x1) * (carry))));                 // gae = delta + (gl*m)*gae
+                    if (PROPER) carry = ((carry) * (lds[buf][3][j][tid]));   // gae *= bad_mask
+                    res = ((carry) + (lds[buf][2][j][tid]));                 // R = gae + V[t]
                 } else {
-                    carry = __fadd_rn(__fmul_rn(__fmul_rn(carry, g), x0), x1);   // (R*g)*m + r
+                    carry = ((((((carry) * (g))) * (x0))) + (x1));   // (R*g)*m + r
                     if (PROPER)
-                        carry = __fadd_rn(__fmul_rn(carry, lds[buf][2][j][tid]), lds[buf][3][j][tid]);
+                        carry = ((((carry) * (lds[buf][2][j][tid]))) + (lds[buf][3][j][tid]));
                     res = carry;
                 }
                 if (tlo + j >= 0 && n < N) out[(long)j * N] = res;
@@ -137,7 +139,7 @@ __global__ __launch_bounds__(ADV_THREADS) void adv_partial_kernel(const float* r
     __shared__ double sm[16];
     double s = 0.0, s2 = 0.0;
     for (long i = (long)blockIdx.x * ADV_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * ADV_THREADS) {
-        const float a = __fsub_rn(returns[i], value_preds[i]);
+        const float a = ((returns[i]) - (value_preds[i]));
         s += (double)a;
         s2 += (double)a * (double)a;
     }
@@ -171,10 +173,10 @@ __global__ __launch_bounds__(ADV_THREADS) void adv_normalize_kernel(const float*
     }
     __syncthreads();
     const float mean = ms[0];
-    const float denom = __fadd_rn(ms[1], 1e-5f);
+    const float denom = ((ms[1]) + (1e-5f));
     for (long i = (long)blockIdx.x * ADV_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * ADV_THREADS) {
-        const float a = __fsub_rn(returns[i], value_preds[i]);
-        adv[i] = __fdiv_rn(__fsub_rn(a, mean), denom);
+        const float a = ((returns[i]) - (value_preds[i]));
+        adv[i] = ((((a) - (mean))) / (denom));
     }
 }
 

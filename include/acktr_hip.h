@@ -54,6 +54,50 @@ int acktr_adv_normalize_f32(const float* returns, const float* value_preds, floa
 int acktr_gather_rows(const void* src, const int64_t* idx, void* dst, long rows, long row_bytes, long src_rows,
                       void* stream);
 
+/* ---- policy network operators (fp32 MFMA implicit GEMM) ---------------------------------- */
+
+/* nn.Conv2d forward of CNNBase -- a2c_ppo_acktr/model.py:176-179,190.
+ * y[B,OC,OH,OW] = relu?( in_scale * conv(x, w) + bias ), NCHW, no padding.  Supported geometries:
+ * (H=W=84,K=8,S=4), (H=W=20,K=4,S=2), (H=W=9,K=3,S=1); any C, OC.  in_scale folds `inputs / 255.0`.
+ * gather_idx (nullable, int64[B]): image b is read from x + gather_idx[b]*C*H*W -- the minibatch
+ * gather of storage.py:127 fused into the loader.  x, w 16-byte aligned. */
+int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
+                         int B, int C, int H, int W, int OC, int KH, int KW, int S, float in_scale, int relu,
+                         void* stream);
+
+/* autograd backward of the same Conv2d w.r.t. weight and bias: dw[OC,C,KH,KW] = in_scale * sum dy (x) patches,
+ * db[OC] = sum dy (db nullable).  Split-K slabs live in `workspace` (see ..._workspace_bytes); the
+ * slab reduction is fixed-order, so results are run-to-run deterministic. */
+long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, int OC, int KH, int KW, int S);
+int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw, float* db, int B,
+                           int C, int H, int W, int OC, int KH, int KW, int S, float in_scale, void* workspace,
+                           long workspace_bytes, void* stream);
+
+/* autograd backward w.r.t. the input: dx[B,C,H,W] = conv_transpose(dy, w) (* (x_act > 0) when x_act is
+ * given: the ReLU backward of the layer that produced x, model.py:177-179). */
+int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
+                           int OC, int KH, int KW, int S, void* stream);
+
+/* nn.Linear forward -- model.py:180,185,208-216, distributions.py:69,83.
+ * y[B,OUT] = act(x[B,IN] w[OUT,IN]^T + bias);  act: 0 none, 1 relu, 2 tanh. */
+int acktr_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int IN, int OUT, int act,
+                         void* stream);
+/* dx[B,IN] (=|+=) (dy[B,OUT] w[OUT,IN]) * gate;  gate: 0 none, 1 relu' (gate_src > 0), 2 tanh' (1 - gate_src^2),
+ * gate_src[B,IN] = the activation that feeds this layer. */
+int acktr_linear_dgrad_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx, int B, int IN,
+                           int OUT, int accumulate, void* stream);
+/* dw[OUT,IN] = dy^T x ; db[OUT] = column sums of dy (db nullable). */
+long acktr_linear_wgrad_workspace_bytes(int B, int IN, int OUT);
+int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT,
+                           void* workspace, long workspace_bytes, void* stream);
+
+/* Strided fp32 GEMM  C[M,N] (=|+=) alpha * sum_k A(m,k) B(n,k); each operand contiguous along k
+ * (stride_k == 1) or along its row index (stride_row == 1).  Used for the KFAC Kronecker-eigenbasis
+ * products of a2c_ppo_acktr/algo/kfac.py:221-224. */
+int acktr_gemm_f32(const float* a, long a_stride_row, long a_stride_k, const float* b, long b_stride_row,
+                   long b_stride_k, float* c, long ldc, int M, int N, int K, float alpha, int accumulate,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,140 @@
+"""Tensor-level wrappers over the C-ABI operators (include/acktr_hip.h).
+
+Thin plumbing only: shape checks on the host (a wrong shape must never reach a
+kernel), device pointers + the current stream handed to the library.  Every
+function requires fp32 contiguous GPU tensors and raises otherwise.
+"""
+import torch
+
+from . import _hip
+
+f32 = torch.float32
+_ws_cache = {}
+
+
+def workspace(device, nbytes, tag='ws'):
+    """Per-(device, tag) scratch buffer, grown on demand and reused across calls."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _p(t, name, dtype=f32):
+    return _hip.dev_ptr(t, dtype, name)
+
+
+def _conv_out(H, K, S):
+    return (H - K) // S + 1
+
+
+def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out=None):
+    """y = relu?(in_scale*conv2d(x[gather_idx], w) + bias); x [Bsrc,C,H,W], w [OC,C,KH,KW]."""
+    OC, C, KH, KW = w.shape
+    H, W = x.shape[-2], x.shape[-1]
+    assert x.shape[-3] == C, 'channel mismatch'
+    B = x.shape[0] if gather_idx is None else gather_idx.numel()
+    OH, OW = _conv_out(H, KH, stride), _conv_out(W, KW, stride)
+    if out is None:
+        out = torch.empty(B, OC, OH, OW, dtype=f32, device=x.device)
+    assert out.shape == (B, OC, OH, OW)
+    rc = _hip.lib().acktr_conv2d_fwd_f32(
+        _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
+        B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0, _hip.cur_stream(x.device))
+    _hip.check(rc, 'acktr_conv2d_fwd_f32')
+    return out
+
+
+def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=None):
+    OC, C, KH, KW = w_shape
+    H, W = x.shape[-2], x.shape[-1]
+    B = dy.shape[0]
+    assert dy.shape == (B, OC, _conv_out(H, KH, stride), _conv_out(W, KW, stride))
+    assert dw.numel() == OC * C * KH * KW and (db is None or db.numel() == OC)
+    if gather_idx is None:
+        assert x.shape[0] == B
+    else:
+        assert gather_idx.numel() == B
+    L = _hip.lib()
+    nbytes = L.acktr_conv2d_wgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride)
+    ws = workspace(x.device, nbytes)
+    rc = L.acktr_conv2d_wgrad_f32(
+        _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(dy, 'dy'), _p(dw, 'dw'), _p(db, 'db'),
+        B, C, H, W, OC, KH, KW, stride, float(in_scale), _p(ws, 'workspace', torch.uint8), ws.numel(),
+        _hip.cur_stream(x.device))
+    _hip.check(rc, 'acktr_conv2d_wgrad_f32')
+
+
+def conv2d_dgrad(dy, w, x_act, stride, out=None):
+    """dx = conv_transpose(dy, w) * (x_act > 0); x_act [B,C,H,W] is the (post-ReLU) input of the layer."""
+    OC, C, KH, KW = w.shape
+    B, _, OH, OW = dy.shape
+    H, W = (OH - 1) * stride + KH, (OW - 1) * stride + KW
+    if out is None:
+        out = torch.empty(B, C, H, W, dtype=f32, device=dy.device)
+    assert out.shape == (B, C, H, W) and (x_act is None or x_act.shape == out.shape)
+    rc = _hip.lib().acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
+                                           B, C, H, W, OC, KH, KW, stride, _hip.cur_stream(dy.device))
+    _hip.check(rc, 'acktr_conv2d_dgrad_f32')
+    return out
+
+
+ACT = {None: 0, 'none': 0, 'relu': 1, 'tanh': 2}
+
+
+def linear_fwd(x, w, bias, act=None, out=None):
+    B, IN = x.shape
+    OUT = w.shape[0]
+    assert w.shape[1] == IN
+    if out is None:
+        out = torch.empty(B, OUT, dtype=f32, device=x.device)
+    rc = _hip.lib().acktr_linear_fwd_f32(_p(x, 'x'), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'), B, IN, OUT,
+                                         ACT[act], _hip.cur_stream(x.device))
+    _hip.check(rc, 'acktr_linear_fwd_f32')
+    return out
+
+
+def linear_dgrad(dy, w, gate_src=None, gate=None, out=None, accumulate=False):
+    B, OUT = dy.shape
+    IN = w.shape[1]
+    assert w.shape[0] == OUT
+    if out is None:
+        assert not accumulate
+        out = torch.empty(B, IN, dtype=f32, device=dy.device)
+    rc = _hip.lib().acktr_linear_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(gate_src, 'gate_src'), ACT[gate],
+                                           _p(out, 'dx'), B, IN, OUT, 1 if accumulate else 0,
+                                           _hip.cur_stream(dy.device))
+    _hip.check(rc, 'acktr_linear_dgrad_f32')
+    return out
+
+
+def linear_wgrad(dy, x, dw, db=None):
+    B, OUT = dy.shape
+    IN = x.shape[1]
+    assert x.shape[0] == B and dw.numel() == OUT * IN and (db is None or db.numel() == OUT)
+    L = _hip.lib()
+    ws = workspace(dy.device, L.acktr_linear_wgrad_workspace_bytes(B, IN, OUT))
+    rc = L.acktr_linear_wgrad_f32(_p(dy, 'dy'), _p(x, 'x'), _p(dw, 'dw'), _p(db, 'db'), B, IN, OUT,
+                                  _p(ws, 'workspace', torch.uint8), ws.numel(), _hip.cur_stream(dy.device))
+    _hip.check(rc, 'acktr_linear_wgrad_f32')
+
+
+def gemm(a, b, out=None, trans_a=False, trans_b=False, alpha=1.0, accumulate=False):
+    """out (=|+=) alpha * op(a) @ op(b) for 2-D contiguous fp32 GPU tensors (op = transpose if trans_*)."""
+    M, K = (a.shape[1], a.shape[0]) if trans_a else a.shape
+    K2, N = (b.shape[1], b.shape[0]) if trans_b else b.shape
+    assert K == K2, 'inner dimensions differ'
+    if out is None:
+        assert not accumulate
+        out = torch.empty(M, N, dtype=f32, device=a.device)
+    assert out.shape == (M, N) and out.is_contiguous()
+    # A(m,k): a[m,k] -> (row stride lda, k stride 1); transposed: a[k,m] -> (row stride 1, k stride lda)
+    a_sr, a_sk = (1, a.shape[1]) if trans_a else (a.shape[1], 1)
+    # B(n,k) = op(b)[k,n]: b[k,n] -> (row stride 1, k stride ldb); transposed: b[n,k] -> (row stride ldb, k stride 1)
+    b_sr, b_sk = (b.shape[1], 1) if trans_b else (1, b.shape[1])
+    rc = _hip.lib().acktr_gemm_f32(_p(a, 'a'), a_sr, a_sk, _p(b, 'b'), b_sr, b_sk, _p(out, 'c'), N, M, N, K,
+                                   float(alpha), 1 if accumulate else 0, _hip.cur_stream(a.device))
+    _hip.check(rc, 'acktr_gemm_f32')
+    return out

@@ -1,0 +1,303 @@
+// fp32 MFMA tile-GEMM skeleton with pluggable operand loaders and epilogues (gfx950).
+//
+//   C(m, n) = sum_k  Mop(m, k) * Nop(n, k)          m: 32x32 tile rows (accumulator registers)
+//                                                   n: 32x32 tile cols (lanes -> coalesced stores)
+//
+// Every dense contraction of the update path (implicit-GEMM convolution forward / dgrad /
+// wgrad, linear layers, KFAC factor SYRKs, KFAC preconditioning) is this one skeleton with a
+// different pair of *operand functors*: an operand never has to exist in memory as a matrix --
+// im2col patches, transposed views, gathered minibatch rows are address functions evaluated by
+// the loader, so no patch matrix is ever materialised in HBM.
+//
+// MI355X specifics
+//   * v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 64 FLOP/clk/SIMD = the fp32 matrix peak);
+//     64-wide waves, 4 waves / workgroup arranged WM x WN over the block tile.
+//   * K-permutation trick: lane half h owns k = 8q+4h .. 8q+4h+3 of every 8-wide k group, so one
+//     ds_read_b128 per operand feeds FOUR MFMA k-steps (both operands use the same permutation,
+//     so products pair up correctly; only the fp32 summation order changes).
+//   * LDS layouts follow the operand's memory contiguity so global loads stay 16 B wide:
+//       INNER_IS_K  : [rows][32+4]   (k contiguous)  fragment = 1 x ds_read_b128, conflict free
+//       !INNER_IS_K : [32][rows+4]   (row contiguous) fragment = 4 x ds_read_b32, conflict free
+//   * register-staged double buffering: global loads of tile t+1 are issued before the MFMAs of
+//     tile t and written to the other LDS stage afterwards; one barrier per K tile.
+//   * optional split-K over blockIdx.z into per-slice slabs (deterministic fixed-order reduce).
+#pragma once
+#include "common.hpp"
+
+namespace acktr {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int GK = 32;        // K tile
+constexpr int PK = GK + 4;    // pitch (floats) of the k-contiguous LDS layout
+
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// ------------------------------------------------------------------------------------------
+// Operand tile: global -> registers -> LDS -> MFMA fragments
+// Operand concept:
+//   static constexpr bool INNER_IS_K;
+//   struct Outer;  Outer prep(int outer) const;
+//   f32x4 ld4(const Outer&, int inner4) const;     // 4 consecutive "inner" elements, 0-filled OOB
+//   INNER_IS_K : outer = row (m or n), inner = k        !INNER_IS_K : outer = k, inner = row
+// ------------------------------------------------------------------------------------------
+template <int BR, class Op>
+struct OperandTile {
+    static constexpr int UNITS = BR / 32;            // float4 units per thread per K tile
+    static constexpr int PITCH_R = BR + 4;
+    static constexpr int SMEM = Op::INNER_IS_K ? BR * PK : GK * PITCH_R;
+    static constexpr int RQ = BR / 4;                // row-contiguous layout: float4 groups per k row
+    static constexpr int KSTEP = 256 / RQ;
+
+    f32x4 regs[UNITS];
+    typename Op::Outer outer[Op::INNER_IS_K ? UNITS : 1];
+
+    __device__ __forceinline__ void init(const Op& op, int row_base, int tid) {
+        if constexpr (Op::INNER_IS_K) {
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) outer[u] = op.prep(row_base + (tid >> 3) + 32 * u);
+        }
+    }
+    __device__ __forceinline__ void load(const Op& op, int row_base, int k_base, int tid) {
+        if constexpr (Op::INNER_IS_K) {
+            const int k0 = k_base + 4 * (tid & 7);
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) regs[u] = op.ld4(outer[u], k0);
+        } else {
+            const int r0 = row_base + 4 * (tid % RQ);
+            const int k = k_base + tid / RQ;
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) regs[u] = op.ld4(op.prep(k + KSTEP * u), r0);
+        }
+    }
+    __device__ __forceinline__ void store(float* s, int tid) const {
+        if constexpr (Op::INNER_IS_K) {
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u)
+                *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * u) * PK + 4 * (tid & 7)) = regs[u];
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u)
+                *reinterpret_cast<f32x4*>(s + (tid / RQ + KSTEP * u) * PITCH_R + 4 * (tid % RQ)) = regs[u];
+        }
+    }
+    // fragment for tile-local row `row`, k group base kk = 8q + 4h
+    __device__ static __forceinline__ f32x4 frag(const float* s, int row, int kk) {
+        if constexpr (Op::INNER_IS_K) {
+            return *reinterpret_cast<const f32x4*>(s + row * PK + kk);
+        } else {
+            f32x4 v;
+            v[0] = s[(kk + 0) * PITCH_R + row];
+            v[1] = s[(kk + 1) * PITCH_R + row];
+            v[2] = s[(kk + 2) * PITCH_R + row];
+            v[3] = s[(kk + 3) * PITCH_R + row];
+            return v;
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------
+// Epilogue concept:
+//   struct Col;  Col col(int n) const;                       // per-lane column state (validity, offsets)
+//   void st(const Col&, int m, float acc, int kslice) const; // bounds-checks m itself
+// ------------------------------------------------------------------------------------------
+template <int BM, int BN, int WM, int WN, class MOp, class NOp, class Epi>
+__global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const NOp nop, const Epi epi, int K,
+                                                            int kchunk) {
+    static_assert(WM * WN == 4, "4 waves per workgroup");
+    static_assert(BM % (32 * WM) == 0 && BN % (32 * WN) == 0, "tile / wave layout");
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    using MT = OperandTile<BM, MOp>;
+    using NT = OperandTile<BN, NOp>;
+    constexpr int STAGE = MT::SMEM + NT::SMEM;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int kbeg = blockIdx.z * kchunk;
+    int kend = kbeg + kchunk;
+    if (kend > K) kend = K;
+    const int nk = (kend - kbeg + GK - 1) / GK;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    MT mt;
+    NT nt;
+    mt.init(mop, m0, tid);
+    nt.init(nop, n0, tid);
+
+    if (nk > 0) {
+        mt.load(mop, m0, kbeg, tid);
+        nt.load(nop, n0, kbeg, tid);
+        mt.store(smem, tid);
+        nt.store(smem + MT::SMEM, tid);
+    }
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const float* sM = smem + (kt & 1) * STAGE;
+        const float* sN = sM + MT::SMEM;
+        const bool more = (kt + 1 < nk);
+        if (more) {
+            mt.load(mop, m0, kbeg + (kt + 1) * GK, tid);
+            nt.load(nop, n0, kbeg + (kt + 1) * GK, tid);
+        }
+#pragma unroll
+        for (int q = 0; q < GK / 8; ++q) {
+            const int kk = 8 * q + 4 * lh;
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[a] = MT::frag(sM, wm * (TM * 32) + a * 32 + li, kk);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[b] = NT::frag(sN, wn * (TN * 32) + b * 32 + li, kk);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int a = 0; a < TM; ++a)
+#pragma unroll
+                    for (int b = 0; b < TN; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+        }
+        if (more) {
+            float* dM = smem + ((kt + 1) & 1) * STAGE;
+            mt.store(dM, tid);
+            nt.store(dM + MT::SMEM, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane -> column n, registers -> rows m
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn * (TN * 32) + b * 32 + li;
+        const typename Epi::Col col = epi.col(n);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            const int mb = m0 + wm * (TM * 32) + a * 32 + 4 * lh;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], (int)blockIdx.z);
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN, class MOp, class NOp, class Epi>
+int launch_gemm(const MOp& mop, const NOp& nop, const Epi& epi, int M, int N, int K, int nslices,
+                hipStream_t stream) {
+    using MT = OperandTile<BM, MOp>;
+    using NT = OperandTile<BN, NOp>;
+    constexpr int smem_bytes = 2 * (MT::SMEM + NT::SMEM) * (int)sizeof(float);
+    static_assert(smem_bytes <= 160 * 1024, "LDS budget");
+    if (M <= 0 || N <= 0) return 0;
+    if (nslices < 1) nslices = 1;
+    int kchunk = (K + nslices - 1) / nslices;
+    kchunk = ((kchunk + GK - 1) / GK) * GK;
+    if (kchunk < GK) kchunk = GK;
+    auto kern = gemm_mfma_f32_kernel<BM, BN, WM, WN, MOp, NOp, Epi>;
+    if (smem_bytes > 48 * 1024) {
+        static bool attr_set = false;   // per instantiation
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+            if (e != hipSuccess) {
+                set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem_bytes, hipGetErrorString(e));
+                return (int)e;
+            }
+            attr_set = true;
+        }
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), nslices);
+    if (grid.y > 65535 || grid.z > 65535) {
+        set_error("gemm grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
+        return -1;
+    }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem_bytes, stream, mop, nop, epi, K, kchunk);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+// ==========================================================================================
+// Dense operands
+// ==========================================================================================
+// element (row, k) at p[row*ld + k]  (k contiguous)
+struct DenseKC {
+    static constexpr bool INNER_IS_K = true;
+    const float* p; int rows; int K; long ld; int vec;
+    struct Outer { const float* rp; int ok; };
+    __device__ __forceinline__ Outer prep(int row) const {
+        Outer o; o.ok = row < rows; o.rp = p + (long)(o.ok ? row : 0) * ld; return o;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, int k0) const {
+        f32x4 v = zero4();
+        if (!o.ok || k0 >= K) return v;
+        if (vec && k0 + 3 < K) return *reinterpret_cast<const f32x4*>(o.rp + k0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (k0 + j < K) v[j] = o.rp[k0 + j];
+        return v;
+    }
+};
+// element (row, k) at p[k*ld + row]  (row contiguous)
+struct DenseRC {
+    static constexpr bool INNER_IS_K = false;
+    const float* p; int rows; int K; long ld; int vec;
+    struct Outer { const float* kp; int ok; };
+    __device__ __forceinline__ Outer prep(int k) const {
+        Outer o; o.ok = k < K; o.kp = p + (long)(o.ok ? k : 0) * ld; return o;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, int r0) const {
+        f32x4 v = zero4();
+        if (!o.ok || r0 >= rows) return v;
+        if (vec && r0 + 3 < rows) return *reinterpret_cast<const f32x4*>(o.kp + r0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = o.kp[r0 + j];
+        return v;
+    }
+};
+static inline int vec_ok(const float* p, long ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
+
+// ==========================================================================================
+// Row-major epilogue: C[slab][m*ldc + n] = post(acc)
+//   v = acc*scale (+ bias_n[n]) (+ bias_m[m]);  act: 0 none, 1 relu, 2 tanh
+//   gate: 0 none, 1 relu'  (v *= gate_src[m*ldg+n] > 0), 2 tanh' (v *= 1 - gate_src^2)
+//   accumulate: C += v (single slice only)
+// ==========================================================================================
+struct RowMajorEpi {
+    float* c; int M; int N; long ldc; long slab_stride;
+    const float* bias_n; const float* bias_m; float scale; int act;
+    const float* gate_src; long ldg; int gate; int accumulate;
+    struct Col { int n; int ok; float bn; };
+    __device__ __forceinline__ Col col(int n) const {
+        Col cc; cc.n = n; cc.ok = n < N; cc.bn = (cc.ok && bias_n) ? bias_n[n] : 0.f; return cc;
+    }
+    __device__ __forceinline__ void st(const Col& cc, int m, float acc, int ks) const {
+        if (!cc.ok || m >= M) return;
+        float v = acc * scale + cc.bn;
+        if (bias_m) v += bias_m[m];
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        else if (act == 2) v = tanhf(v);
+        if (gate == 1) v = gate_src[(long)m * ldg + cc.n] > 0.f ? v : 0.f;
+        else if (gate == 2) { const float h = gate_src[(long)m * ldg + cc.n]; v = v * (1.f - h * h); }
+        float* d = c + (long)ks * slab_stride + (long)m * ldc + cc.n;
+        if (accumulate) v += *d;
+        *d = v;
+    }
+};
+static inline RowMajorEpi row_major_epi(float* c, int M, int N, long ldc) {
+    RowMajorEpi e; e.c = c; e.M = M; e.N = N; e.ldc = ldc; e.slab_stride = 0; e.bias_n = nullptr; e.bias_m = nullptr;
+    e.scale = 1.f; e.act = 0; e.gate_src = nullptr; e.ldg = 0; e.gate = 0; e.accumulate = 0; return e;
+}
+
+// Fixed-order slab reduction: dst[i] (=|+=) scale * sum_s slabs[s*stride + i]
+int launch_slab_reduce(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,
+                       hipStream_t stream);
+
+}  // namespace acktr

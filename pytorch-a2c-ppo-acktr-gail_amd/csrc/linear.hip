@@ -1,0 +1,173 @@
+// Linear layers (forward / dgrad / wgrad / bias grad) on the fp32 MFMA tile GEMM, plus the shared
+// fixed-order slab reduction.  Replaces the torch.nn.Linear call sites of the reference policy:
+// model.py:180,185,208-216 and distributions.py:69,83 (forward) and their autograd backward.
+#include "gemm_core.hpp"
+#include "../../include/acktr_hip.h"
+
+namespace acktr {
+
+__global__ __launch_bounds__(256) void slab_reduce_kernel(float* dst, const float* slabs, int nslabs, long n,
+                                                          long stride, float scale, int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < nslabs; ++k) s += slabs[(long)k * stride + i];   // fixed order: deterministic
+        s *= scale;
+        if (accumulate) s += dst[i];
+        dst[i] = s;
+    }
+}
+
+int launch_slab_reduce(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,
+                       hipStream_t stream) {
+    if (n <= 0) return 0;
+    int blocks = cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, dst, slabs, nslabs, n, stride, scale,
+                       accumulate);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+// column sums of a row-major [rows, cols] matrix over a row slice -> partial[slice*cols + col]
+__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* a, int rows, int cols, int rows_per_slice,
+                                                              float* partial) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * rows_per_slice;
+    int r1 = r0 + rows_per_slice;
+    if (r1 > rows) r1 = rows;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += a[(long)r * cols + c];
+    partial[(long)blockIdx.y * cols + c] = s;
+}
+
+template <class MOp, class NOp, class Epi>
+static int gemm_dispatch(const MOp& mop, const NOp& nop, const Epi& epi, int M, int N, int K, int nslices,
+                         hipStream_t s) {
+    if (N <= 64) return launch_gemm<128, 32, 4, 1>(mop, nop, epi, M, N, K, nslices, s);
+    if (M <= 64) return launch_gemm<32, 128, 1, 4>(mop, nop, epi, M, N, K, nslices, s);
+    return launch_gemm<128, 128, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
+}
+
+// Generic C[M,N] (row major, ldc) = A(m,k) * B(n,k) with explicit element strides per operand:
+// an operand is "k contiguous" (stride_k == 1) or "row contiguous" (stride_row == 1).
+int gemm_rowmajor(const float* a, long a_srow, long a_sk, const float* b, long b_srow, long b_sk, const RowMajorEpi& epi,
+                  int M, int N, int K, int nslices, hipStream_t s) {
+    const bool a_kc = (a_sk == 1), b_kc = (b_sk == 1);
+    if (!a_kc && a_srow != 1) { set_error("gemm: operand A must be contiguous along k or rows"); return -1; }
+    if (!b_kc && b_srow != 1) { set_error("gemm: operand B must be contiguous along k or rows"); return -1; }
+    if (a_kc && b_kc) {
+        DenseKC A{a, M, K, a_srow, vec_ok(a, a_srow)}, B{b, N, K, b_srow, vec_ok(b, b_srow)};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    } else if (a_kc && !b_kc) {
+        DenseKC A{a, M, K, a_srow, vec_ok(a, a_srow)};
+        DenseRC B{b, N, K, b_sk, vec_ok(b, b_sk)};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    } else if (!a_kc && b_kc) {
+        DenseRC A{a, M, K, a_sk, vec_ok(a, a_sk)};
+        DenseKC B{b, N, K, b_srow, vec_ok(b, b_srow)};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    } else {
+        DenseRC A{a, M, K, a_sk, vec_ok(a, a_sk)}, B{b, N, K, b_sk, vec_ok(b, b_sk)};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    }
+}
+
+int pick_slices(long tiles, long K, long max_by_ws) {
+    long want = 768 / (tiles > 0 ? tiles : 1);
+    long by_k = K / (4 * GK);              // at least 4 K tiles per slice
+    long n = want;
+    if (n > by_k) n = by_k;
+    if (n > max_by_ws) n = max_by_ws;
+    if (n > 1024) n = 1024;
+    if (n < 1) n = 1;
+    return (int)n;
+}
+
+}  // namespace acktr
+
+using namespace acktr;
+
+extern "C" int acktr_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int IN,
+                                    int OUT, int act, void* stream) {
+    ACKTR_ARG(x && w && y, "linear_fwd: null pointer");
+    ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_fwd: bad sizes B=%d IN=%d OUT=%d", B, IN, OUT);
+    ACKTR_ARG(act >= 0 && act <= 2, "linear_fwd: act must be 0 (none), 1 (relu) or 2 (tanh)");
+    RowMajorEpi e = row_major_epi(y, B, OUT, OUT);
+    e.bias_n = bias;
+    e.act = act;
+    return gemm_rowmajor(x, IN, 1, w, IN, 1, e, B, OUT, IN, 1, (hipStream_t)stream);
+}
+
+extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx,
+                                      int B, int IN, int OUT, int accumulate, void* stream) {
+    ACKTR_ARG(dy && w && dx, "linear_dgrad: null pointer");
+    ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_dgrad: bad sizes");
+    ACKTR_ARG(gate >= 0 && gate <= 2 && (gate == 0 || gate_src), "linear_dgrad: gate needs gate_src");
+    RowMajorEpi e = row_major_epi(dx, B, IN, IN);
+    e.gate = gate; e.gate_src = gate_src; e.ldg = IN; e.accumulate = accumulate;
+    // dX[b, i] = sum_o dY[b, o] * W[o, i]   : A = dY (k contiguous), B(n=i, k=o) = W[o*IN + i] (row contiguous)
+    return gemm_rowmajor(dy, OUT, 1, w, 1, IN, e, B, IN, OUT, 1, (hipStream_t)stream);
+}
+
+extern "C" long acktr_linear_wgrad_workspace_bytes(int B, int IN, int OUT) {
+    const long tiles = (long)cdiv(OUT, 128) * cdiv(IN, 128);
+    const int ns = pick_slices(tiles, B, 1024);
+    return ((long)ns * OUT * IN + (long)64 * OUT) * (long)sizeof(float);
+}
+
+extern "C" int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT,
+                                      void* workspace, long workspace_bytes, void* stream) {
+    ACKTR_ARG(dy && x && dw, "linear_wgrad: null pointer");
+    ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_wgrad: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const long ws_floats = workspace ? workspace_bytes / (long)sizeof(float) : 0;
+    const long bias_floats = db ? (long)64 * OUT : 0;
+    const long tiles = (long)cdiv(OUT, 128) * cdiv(IN, 128);
+    long max_by_ws = (ws_floats - bias_floats) / ((long)OUT * IN);
+    if (max_by_ws < 1) max_by_ws = 1;
+    int ns = pick_slices(tiles, B, max_by_ws);
+    if (ns > 1 && (ws_floats - bias_floats) < (long)ns * OUT * IN) ns = 1;
+    // dW[o, i] = sum_b dY[b, o] * X[b, i] : A(m=o, k=b) = dy[b*OUT + o], B(n=i, k=b) = x[b*IN + i]
+    int rc;
+    if (ns == 1) {
+        RowMajorEpi e = row_major_epi(dw, OUT, IN, IN);
+        rc = gemm_rowmajor(dy, 1, OUT, x, 1, IN, e, OUT, IN, B, 1, s);
+        if (rc) return rc;
+    } else {
+        RowMajorEpi e = row_major_epi(ws, OUT, IN, IN);
+        e.slab_stride = (long)OUT * IN;
+        rc = gemm_rowmajor(dy, 1, OUT, x, 1, IN, e, OUT, IN, B, ns, s);
+        if (rc) return rc;
+        rc = launch_slab_reduce(dw, ws, ns, (long)OUT * IN, (long)OUT * IN, 1.f, 0, s);
+        if (rc) return rc;
+    }
+    if (db) {
+        ACKTR_ARG(ws_floats >= bias_floats + (ns > 1 ? (long)ns * OUT * IN : 0),
+                  "linear_wgrad: workspace too small for the bias partials (%ld floats)", ws_floats);
+        float* part = ws + (ns > 1 ? (long)ns * OUT * IN : 0);
+        int nsl = cdiv(B, 64);
+        if (nsl > 64) nsl = 64;
+        const int rps = cdiv(B, nsl);
+        nsl = cdiv(B, rps);
+        hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(OUT, 256), nsl), dim3(256), 0, s, dy, B, OUT, rps, part);
+        ACKTR_LAUNCH_CHECK();
+        rc = launch_slab_reduce(db, part, nsl, OUT, OUT, 1.f, 0, s);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
+/* Generic strided fp32 GEMM: C[M,N] = alpha * A(m,k) B(n,k) (+ beta*C), used by the KFAC preconditioner.
+ * Each operand must be contiguous along k or along its row index. */
+extern "C" int acktr_gemm_f32(const float* a, long a_stride_row, long a_stride_k, const float* b, long b_stride_row,
+                              long b_stride_k, float* c, long ldc, int M, int N, int K, float alpha, int accumulate,
+                              void* stream) {
+    ACKTR_ARG(a && b && c, "gemm: null pointer");
+    ACKTR_ARG(M > 0 && N > 0 && K > 0 && ldc >= N, "gemm: bad sizes M=%d N=%d K=%d ldc=%ld", M, N, K, ldc);
+    RowMajorEpi e = row_major_epi(c, M, N, ldc);
+    e.scale = alpha;
+    e.accumulate = accumulate;
+    return gemm_rowmajor(a, a_stride_row, a_stride_k, b, b_stride_row, b_stride_k, e, M, N, K, 1, (hipStream_t)stream);
+}

@@ -1,0 +1,140 @@
+"""GPU parity of the operator-level C-ABI entry points against plain torch fp32 CPU ops
+(the ops the reference calls at model.py:176-195; floating point -> tolerance 2e-5 relative L2,
+well inside the 1e-4 loss/gradient budget of BASELINE.json)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def rel(a, b):
+    a = a.detach().cpu().double().reshape(-1)
+    b = b.detach().cpu().double().reshape(-1)
+    return float((a - b).norm() / max(float(b.norm()), 1e-30))
+
+
+GEOMS = [(84, 8, 4), (20, 4, 2), (9, 3, 1)]
+
+
+@pytest.mark.parametrize('H,K,S', GEOMS)
+@pytest.mark.parametrize('B,C,OC', [(1, 4, 32), (5, 32, 64), (33, 64, 32), (7, 3, 40)])
+def test_conv2d_fwd_wgrad_dgrad(H, K, S, B, C, OC):
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(H * 1000 + B)
+    x = torch.rand(B, C, H, H, generator=g) * (255.0 if H == 84 else 1.0)
+    x = torch.relu(x - (0.3 if H != 84 else 0.0))          # post-ReLU-like inputs with exact zeros
+    w = torch.randn(OC, C, K, K, generator=g) / np.sqrt(C * K * K)
+    b = torch.randn(OC, generator=g) * 0.1
+    scale = 1.0 / 255.0 if H == 84 else 1.0
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    y_ref = F.relu(F.conv2d(xr * scale, wr, br, stride=S))
+    dy = torch.randn(y_ref.shape, generator=g)
+    dy_pre = dy * (y_ref > 0).float()
+    y_ref.backward(dy)
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y = ops.conv2d_fwd(xd, wd, bd, S, in_scale=scale, relu=True)
+    assert rel(y, y_ref) < TOL
+    dw = torch.empty_like(wd)
+    db = torch.empty_like(bd)
+    ops.conv2d_wgrad(xd, dy_pre.cuda(), tuple(w.shape), S, dw, db, in_scale=scale)
+    assert rel(dw, wr.grad) < TOL
+    assert rel(db, br.grad) < TOL
+    # dgrad (without the producing layer's relu gate, then with it)
+    dx = ops.conv2d_dgrad(dy_pre.cuda(), wd, None, S)
+    assert rel(dx * scale, xr.grad) < TOL
+    dxg = ops.conv2d_dgrad(dy_pre.cuda(), wd, xd, S)
+    assert rel(dxg * scale, xr.grad * (x > 0).float()) < TOL
+
+
+def test_conv1_gather_fused():
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(11)
+    store = torch.randint(0, 256, (40, 4, 84, 84), generator=g).float()
+    idx = torch.randperm(40, generator=g)[:13]
+    w = torch.randn(32, 4, 8, 8, generator=g) / 16
+    b = torch.randn(32, generator=g) * 0.1
+    y_ref = F.relu(F.conv2d(store[idx] / 255.0, w, b, stride=4))
+    y = ops.conv2d_fwd(store.cuda(), w.cuda(), b.cuda(), 4, in_scale=1 / 255.0, relu=True, gather_idx=idx.cuda())
+    assert rel(y, y_ref) < TOL
+    dy = torch.randn(y_ref.shape, generator=g)
+    wr = w.clone().requires_grad_(True)
+    F.conv2d(store[idx] / 255.0, wr, b, stride=4).backward(dy)
+    dw = torch.empty(32, 4, 8, 8, device='cuda')
+    ops.conv2d_wgrad(store.cuda(), dy.cuda(), (32, 4, 8, 8), 4, dw, None, in_scale=1 / 255.0, gather_idx=idx.cuda())
+    assert rel(dw, wr.grad) < TOL
+
+
+def test_conv_wgrad_large_batch_split_k_deterministic():
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(5)
+    B = 300
+    x = torch.rand(B, 32, 20, 20, generator=g)
+    dy = torch.randn(B, 64, 9, 9, generator=g)
+    wr = torch.zeros(64, 32, 4, 4, requires_grad=True)
+    F.conv2d(x, wr, None, stride=2).backward(dy)
+    dw1 = torch.empty(64, 32, 4, 4, device='cuda')
+    dw2 = torch.empty_like(dw1)
+    ops.conv2d_wgrad(x.cuda(), dy.cuda(), (64, 32, 4, 4), 2, dw1)
+    ops.conv2d_wgrad(x.cuda(), dy.cuda(), (64, 32, 4, 4), 2, dw2)
+    assert rel(dw1, wr.grad) < TOL
+    assert torch.equal(dw1, dw2), 'split-K reduction must be run-to-run deterministic'
+
+
+@pytest.mark.parametrize('B,IN,OUT', [(1, 11, 64), (64, 64, 64), (80, 1568, 512), (256, 512, 7), (1000, 1568, 512),
+                                      (64, 64, 3), (130, 17, 64), (33, 512, 1)])
+@pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
+def test_linear_fwd_bwd(B, IN, OUT, act):
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(B + IN)
+    x0 = torch.randn(B, IN, generator=g)
+    xin = torch.relu(x0) if act == 'relu' else torch.tanh(x0)      # the activation that feeds the layer
+    w = torch.randn(OUT, IN, generator=g) / np.sqrt(IN)
+    b = torch.randn(OUT, generator=g) * 0.1
+    xr, wr, br = xin.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.linear(xr, wr, br)
+    if act == 'relu':
+        y_ref = F.relu(y_ref)
+    elif act == 'tanh':
+        y_ref = torch.tanh(y_ref)
+    y = ops.linear_fwd(xin.cuda(), w.cuda(), b.cuda(), act)
+    assert rel(y, y_ref) < TOL
+    dy = torch.randn(B, OUT, generator=g)
+    y_ref.backward(dy)
+    if act == 'relu':
+        dpre = dy * (y_ref > 0).float()
+    elif act == 'tanh':
+        dpre = dy * (1 - y_ref.detach() ** 2)
+    else:
+        dpre = dy
+    dw = torch.empty(OUT, IN, device='cuda')
+    db = torch.empty(OUT, device='cuda')
+    ops.linear_wgrad(dpre.cuda(), xin.cuda(), dw, db)
+    assert rel(dw, wr.grad) < TOL
+    assert rel(db, br.grad) < TOL
+    dx = ops.linear_dgrad(dpre.cuda(), w.cuda())
+    assert rel(dx, xr.grad) < TOL
+    gate = act if act else None
+    if gate:
+        dxg = ops.linear_dgrad(dpre.cuda(), w.cuda(), gate_src=xin.cuda(), gate=gate)
+        ref = xr.grad * ((xin > 0).float() if gate == 'relu' else (1 - xin ** 2))
+        assert rel(dxg, ref) < TOL
+
+
+@pytest.mark.parametrize('ta,tb', [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize('M,N,K', [(512, 1568, 512), (6, 512, 6), (33, 65, 97), (1568, 1568, 512)])
+def test_gemm_all_layouts(ta, tb, M, N, K):
+    """A = I-style check with ASYMMETRIC operands: any row/col swap in the MFMA C layout is caught."""
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn((K, M) if ta else (M, K), generator=g)
+    b = torch.randn((N, K) if tb else (K, N), generator=g)
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+    c = ops.gemm(a.cuda(), b.cuda(), trans_a=bool(ta), trans_b=bool(tb))
+    assert rel(c, ref) < TOL
+    c2 = ops.gemm(a.cuda(), b.cuda(), out=c.clone(), trans_a=bool(ta), trans_b=bool(tb), alpha=0.5, accumulate=True)
+    assert rel(c2, 1.5 * ref) < TOL

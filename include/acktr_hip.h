@@ -98,6 +98,67 @@ int acktr_gemm_f32(const float* a, long a_stride_row, long a_stride_k, const flo
                    long b_stride_k, float* c, long ldc, int M, int N, int K, float alpha, int accumulate,
                    void* stream);
 
+/* ---- action distributions and losses ------------------------------------------------------ */
+
+/* Fused loss + backward seeds for one (mini)batch.  Rollout-side arrays (actions, old_logp, old_values,
+ * returns, adv) are indexed through gather_idx (nullable) -- storage.py:127-140 without the copies.
+ *   algo 0: PPO clipped surrogate + (clipped) value loss + entropy        -- algo/ppo.py:61-81
+ *   algo 1: A2C  value_loss = mean((R-v)^2), action_loss = -mean(adv.detach()*logp) -- algo/a2c_acktr.py:48-51,71-72
+ *   algo 2: ACKTR Fisher loss -mean(logp) - mean((v - (v+noise).detach())^2); `adv` carries the noise
+ *                                                                         -- algo/a2c_acktr.py:56-65
+ *   dist 0: Categorical(logits)   -- distributions.py:18-29,71-73 (torch Categorical log_prob / entropy)
+ *   dist 1: DiagGaussian(mean, exp(logstd)) -- distributions.py:36-41,86-95 (torch Normal), A <= 16
+ * Outputs: d(loss)/d(values), d(loss)/d(dist_in) (, d(loss)/d(logstd)), with
+ * loss = value_coef*value_loss + action_loss - entropy_coef*entropy and means taken as sum*inv_batch
+ * (inv_batch = 1/global batch, so data-parallel shards sum to the full-batch gradient);
+ * loss_acc[0..2] += (value_loss, action_loss, entropy) of this batch (as reported by update()). */
+typedef struct acktr_loss_args {
+    int algo, dist, B, A;
+    const float* values;   long ld_values;
+    const float* dist_in;  long ld_dist;
+    const float* logstd;
+    const void* actions;
+    const float* old_logp; const float* old_values; const float* returns; const float* adv;
+    const int64_t* gather_idx;
+    float clip, value_coef, entropy_coef, inv_batch;
+    int use_clipped_value_loss;
+    float* dvalues;  long ld_dvalues;
+    float* ddist;    long ld_ddist;
+    float* dlogstd;
+    float* logp_out;
+    float* loss_acc;
+    void* workspace; long workspace_bytes;
+} acktr_loss_args;
+long acktr_policy_loss_workspace_bytes(int B, int A);
+int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream);
+
+/* dist.log_probs(action) and dist.entropy() per sample -- model.py:74-77 (entropy.mean() is taken by the host). */
+int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions, int B, int A,
+                       float* logp, float* entropy, void* stream);
+/* their backward: ddist = dlogp[b]*dlogp/d(dist_in) + dentropy[b]*dentropy/d(dist_in) (either seed nullable);
+ * gaussian also returns dlogstd[A] (workspace >= acktr_policy_loss_workspace_bytes(B, A)). */
+int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions,
+                       const float* dlogp, const float* dentropy, int B, int A, float* ddist, long ldd, float* dlogstd,
+                       void* workspace, long workspace_bytes, void* stream);
+
+/* ---- optimisers on flat parameter buffers ------------------------------------------------- */
+
+/* nn.utils.clip_grad_norm_ + optim.Adam.step -- algo/ppo.py:82-84 (max_grad_norm <= 0 disables clipping).
+ * step_size = lr/(1-beta1^t), bias_correction2_sqrt = sqrt(1-beta2^t) are computed by the host in double
+ * (torch/optim/adam.py:529-547).  grads are scaled in place by the clip coefficient, as the reference does.
+ * workspace: acktr_optim_workspace_bytes(). */
+long acktr_optim_workspace_bytes(void);
+int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_grad_norm,
+                        float step_size, float beta1, float beta2, float eps, float bias_correction2_sqrt,
+                        float* total_norm_out, void* workspace, void* stream);
+/* clip_grad_norm_ + optim.RMSprop.step -- algo/a2c_acktr.py:74-78 (torch/optim/rmsprop.py:316-339). */
+int acktr_clip_rmsprop_f32(float* params, float* grads, float* square_avg, long n, float max_grad_norm, float lr,
+                           float alpha, float eps, float* total_norm_out, void* workspace, void* stream);
+/* grads *= *grad_scale_dev (nullable; the KL-clip factor nu of kfac.py:234-239, kept on the device so no host
+ * sync is needed) followed by optim.SGD(momentum).step -- kfac.py:139-142,241 (torch/optim/sgd.py:358-380). */
+int acktr_sgd_momentum_f32(float* params, float* grads, float* momentum_buf, long n, const float* grad_scale_dev,
+                           float lr, float momentum, int first_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -20,6 +20,20 @@ c_i = ctypes.c_int
 c_l = ctypes.c_long
 c_f = ctypes.c_float
 
+
+class LossArgs(ctypes.Structure):
+    """struct acktr_loss_args of include/acktr_hip.h (field order and types must match)."""
+    _fields_ = [('algo', c_i), ('dist', c_i), ('B', c_i), ('A', c_i),
+                ('values', c_p), ('ld_values', c_l), ('dist_in', c_p), ('ld_dist', c_l),
+                ('logstd', c_p), ('actions', c_p),
+                ('old_logp', c_p), ('old_values', c_p), ('returns', c_p), ('adv', c_p),
+                ('gather_idx', c_p),
+                ('clip', c_f), ('value_coef', c_f), ('entropy_coef', c_f), ('inv_batch', c_f),
+                ('use_clipped_value_loss', c_i),
+                ('dvalues', c_p), ('ld_dvalues', c_l), ('ddist', c_p), ('ld_ddist', c_l),
+                ('dlogstd', c_p), ('logp_out', c_p), ('loss_acc', c_p),
+                ('workspace', c_p), ('workspace_bytes', c_l)]
+
 # name -> (restype, argtypes); mirrors include/acktr_hip.h one to one
 _PROTOS = {
     'acktr_abi_version': (c_i, []),
@@ -38,6 +52,14 @@ _PROTOS = {
     'acktr_linear_wgrad_workspace_bytes': (c_l, [c_i, c_i, c_i]),
     'acktr_linear_wgrad_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_l, c_p]),
     'acktr_gemm_f32': (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p]),
+    'acktr_policy_loss_workspace_bytes': (c_l, [c_i, c_i]),
+    'acktr_policy_loss_f32': (c_i, [ctypes.POINTER(LossArgs), c_p]),
+    'acktr_dist_fwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    'acktr_dist_bwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_p]),
+    'acktr_optim_workspace_bytes': (c_l, []),
+    'acktr_clip_adam_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
+    'acktr_clip_rmsprop_f32': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
+    'acktr_sgd_momentum_f32': (c_i, [c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_i, c_p]),
 }
 
 

@@ -1,0 +1,93 @@
+"""A2C / ACKTR -- host-side mirror of reference a2c_ppo_acktr/algo/a2c_acktr.py:8-80.
+
+A2C: one full-batch HIP forward, the fused A2C loss kernel, HIP backward, clip-norm + RMSprop in two
+launches.  ACKTR adds the sampled-Fisher backward whose layer inputs / grad-outputs feed the KFAC
+factor kernels, then `KFACOptimizer.step` (algo/kfac.py).
+"""
+import torch
+
+from .. import _hip, engine, ops
+from ..parallel import DataParallel
+
+
+class _FlatRMSprop(object):
+    """optim.RMSprop (alpha, eps; not centred, no momentum) over the flat buffer (torch/optim/rmsprop.py:316-339)."""
+
+    def __init__(self, policy, lr, eps, alpha):
+        self.policy = policy
+        self.param_groups = [{'params': list(policy.parameters()), 'lr': lr, 'eps': eps, 'alpha': alpha}]
+        self.square_avg = None
+
+    def zero_grad(self, set_to_none=False):
+        self.policy.flat_grads.zero_()
+
+    def step(self, max_grad_norm=None):
+        flat, gflat = self.policy.flat_params, self.policy.flat_grads
+        if self.square_avg is None or self.square_avg.device != flat.device or self.square_avg.numel() != flat.numel():
+            self.square_avg = torch.zeros_like(flat)
+        g = self.param_groups[0]
+        L = _hip.lib()
+        ws = ops.workspace(flat.device, L.acktr_optim_workspace_bytes(), 'optim')
+        rc = L.acktr_clip_rmsprop_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.square_avg),
+                                      flat.numel(), float(max_grad_norm) if max_grad_norm else 0.0, g['lr'],
+                                      g['alpha'], g['eps'], None, _hip.dev_ptr(ws), _hip.cur_stream(flat.device))
+        _hip.check(rc, 'acktr_clip_rmsprop_f32')
+
+
+class A2C_ACKTR():
+    def __init__(self,
+                 actor_critic,
+                 value_loss_coef,
+                 entropy_coef,
+                 lr=None,
+                 eps=None,
+                 alpha=None,
+                 max_grad_norm=None,
+                 acktr=False):
+
+        self.actor_critic = actor_critic
+        self.acktr = acktr
+
+        self.value_loss_coef = value_loss_coef
+        self.entropy_coef = entropy_coef
+
+        self.max_grad_norm = max_grad_norm
+
+        if acktr:
+            from .kfac import KFACOptimizer
+            self.optimizer = KFACOptimizer(actor_critic)
+        else:
+            self.optimizer = _FlatRMSprop(actor_critic, lr, eps=eps, alpha=alpha)
+        self.dp = DataParallel()
+
+    def update(self, rollouts):
+        ac = self.actor_critic
+        T, N = rollouts.rewards.size()[0:2]
+        rows = T * N
+        dev = rollouts.rewards.device
+        with torch.no_grad():
+            loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
+            obs_flat = rollouts.obs[:T].view(rows, *rollouts.obs.size()[2:])
+            actions = rollouts.actions.view(rows, -1)
+            returns = rollouts.returns[:T].view(rows)
+            ac.bind_grads()
+            inv_batch = 1.0 / rows
+            idx = None
+            if self.dp.active:                     # shard the full batch over ranks (rows are independent)
+                lo, hi = self.dp.bounds(rows)
+                idx = torch.arange(lo, hi, device=dev)
+            acts = engine.forward(ac, obs_flat, gather_idx=idx)                         # a2c_acktr.py:38-43
+            if self.acktr and self.optimizer.steps % self.optimizer.Ts == 0:
+                self.optimizer.accumulate_stats(acts, actions, idx, inv_batch, self.dp)  # a2c_acktr.py:53-68
+            engine.policy_loss(ac, acts, engine.ALGO_A2C, actions, loss_acc, inv_batch, returns=returns,
+                               gather_idx=idx, value_coef=self.value_loss_coef,
+                               entropy_coef=self.entropy_coef)                          # a2c_acktr.py:48-51,70-72
+            engine.backward(ac, acts, ac.flat_grads)
+            self.dp.all_reduce_sum_(ac.flat_grads)
+            if self.acktr == False:
+                self.optimizer.step(self.max_grad_norm)                                 # a2c_acktr.py:74-78
+            else:
+                self.optimizer.step()
+            self.dp.all_reduce_sum_(loss_acc)
+            vl, al, en = loss_acc.tolist()
+        return vl, al, en

@@ -1,0 +1,281 @@
+"""Forward / backward of the two policy architectures, composed from the C-ABI operators.
+
+CNN  (reference model.py:189-195, distributions.py:71-73):
+    obs/255 -> conv8s4+ReLU -> conv4s2+ReLU -> conv3s1+ReLU -> flatten -> FC+ReLU -> fused head
+    The critic (hidden->1) and the action head (hidden->A) are ONE [1+A, hidden] GEMM because their
+    parameters are adjacent in the flat buffer; `head[:,0]` is the value, `head[:,1:]` the logits.
+MLP  (reference model.py:220-229, distributions.py:86-95):
+    separate tanh towers for critic and actor, value head on the critic tower, mean head on the actor.
+
+`gather_idx` (int64 device tensor) makes every rollout-side read go through the minibatch index, so
+storage.py:127's gathered copies are never made on the NatureCNN path (fused into conv1's loader).
+"""
+import ctypes
+
+import torch
+
+from . import _hip, ops
+
+f32 = torch.float32
+
+
+def _wb(mod):
+    """(weight, bias) parameters of a layer, whether or not KFAC's SplitBias wraps it (kfac.py:74-84)."""
+    if hasattr(mod, 'add_bias') and hasattr(mod, 'module'):
+        return mod.module.weight, mod.add_bias._bias
+    return mod.weight, mod.bias
+
+
+def is_cnn(policy):
+    return hasattr(policy.base, 'main')
+
+
+def cnn_layer_params(policy):
+    m = policy.base.main
+    return {'conv1': _wb(m[0]), 'conv2': _wb(m[2]), 'conv3': _wb(m[4]), 'fc': _wb(m[7]),
+            'critic': _wb(policy.base.critic_linear), 'actor': _wb(policy.dist.linear)}
+
+
+def mlp_layer_params(policy):
+    b = policy.base
+    return {'a0': _wb(b.actor[0]), 'a2': _wb(b.actor[2]), 'c0': _wb(b.critic[0]), 'c2': _wb(b.critic[2]),
+            'critic': _wb(b.critic_linear), 'mean': _wb(policy.dist.fc_mean)}
+
+
+def logstd_param(policy):
+    return policy.dist.logstd._bias
+
+
+class Acts(object):
+    """Activations of one forward pass (kept for the backward and for the KFAC statistics)."""
+
+    def __init__(self, cnn):
+        self.cnn = cnn
+
+    def value(self):
+        return self.head[:, 0:1] if self.cnn else self.v
+
+    def dist_in(self):
+        return self.head[:, 1:] if self.cnn else self.mean
+
+    # raw pointers / leading dimensions for the loss kernels
+    def value_ptr_ld(self):
+        if self.cnn:
+            return self.head.data_ptr(), self.head.shape[1]
+        return self.v.data_ptr(), 1
+
+    def dist_ptr_ld(self):
+        if self.cnn:
+            return self.head.data_ptr() + 4, self.head.shape[1]
+        return self.mean.data_ptr(), self.mean.shape[1]
+
+
+def _check_input(policy, inputs, gather_idx):
+    if not inputs.is_cuda:
+        raise RuntimeError('policy inputs must be on the MI355X device; this package has no CPU path')
+    if next(policy.parameters()).device != inputs.device:
+        raise RuntimeError('policy parameters and inputs are on different devices')
+    if inputs.dtype != f32:
+        raise RuntimeError('policy inputs must be float32 (reference storage.py:12, F6)')
+    if tuple(inputs.shape[1:]) != policy.obs_shape:
+        raise RuntimeError('expected inputs of shape [B, %s], got %s' % (policy.obs_shape, tuple(inputs.shape)))
+
+
+def head_views(policy, flat):
+    """[1+A, hidden] weight and [1+A] bias views of the fused CNN head inside a flat buffer."""
+    L = cnn_layer_params(policy)
+    wc, bc = L['critic']
+    wa, ba = L['actor']
+    ow, _ = policy._offsets[id(wc)]
+    ob, _ = policy._offsets[id(bc)]
+    hidden, A = wc.shape[1], wa.shape[0]
+    return (flat[ow:ow + (1 + A) * hidden].view(1 + A, hidden), flat[ob:ob + 1 + A])
+
+
+def forward(policy, inputs, gather_idx=None):
+    inputs = inputs.contiguous()
+    _check_input(policy, inputs, gather_idx)
+    if is_cnn(policy):
+        L = cnn_layer_params(policy)
+        a = Acts(True)
+        a.obs, a.idx = inputs, gather_idx
+        a.y1 = ops.conv2d_fwd(inputs, L['conv1'][0], L['conv1'][1].view(-1), 4, in_scale=1.0 / 255.0, relu=True,
+                              gather_idx=gather_idx)
+        a.y2 = ops.conv2d_fwd(a.y1, L['conv2'][0], L['conv2'][1].view(-1), 2)
+        a.y3 = ops.conv2d_fwd(a.y2, L['conv3'][0], L['conv3'][1].view(-1), 1)
+        a.flat3 = a.y3.view(a.y3.shape[0], -1)
+        a.feat = ops.linear_fwd(a.flat3, L['fc'][0], L['fc'][1].view(-1), 'relu')
+        wh, bh = head_views(policy, policy.flat_params)
+        a.head = ops.linear_fwd(a.feat, wh, bh, None)
+        return a
+    L = mlp_layer_params(policy)
+    a = Acts(False)
+    if gather_idx is not None:
+        from .storage import RolloutStorage
+        inputs = RolloutStorage._gather(inputs, gather_idx, inputs.shape[0])
+    a.obs = inputs
+    a.hc1 = ops.linear_fwd(inputs, L['c0'][0], L['c0'][1].view(-1), 'tanh')
+    a.hc2 = ops.linear_fwd(a.hc1, L['c2'][0], L['c2'][1].view(-1), 'tanh')
+    a.ha1 = ops.linear_fwd(inputs, L['a0'][0], L['a0'][1].view(-1), 'tanh')
+    a.ha2 = ops.linear_fwd(a.ha1, L['a2'][0], L['a2'][1].view(-1), 'tanh')
+    a.v = ops.linear_fwd(a.hc2, L['critic'][0], L['critic'][1].view(-1), None)
+    a.mean = ops.linear_fwd(a.ha2, L['mean'][0], L['mean'][1].view(-1), None)
+    return a
+
+
+def new_seed_buffers(policy, acts):
+    """d(loss)/d(head outputs) buffers the loss kernels write and backward() consumes."""
+    if acts.cnn:
+        acts.dhead = torch.empty_like(acts.head)
+    else:
+        acts.dv = torch.empty_like(acts.v)
+        acts.dmean = torch.empty_like(acts.mean)
+
+
+def seed_ptrs(acts):
+    """(dvalues ptr, ld, ddist ptr, ld)"""
+    if acts.cnn:
+        ld = acts.dhead.shape[1]
+        return acts.dhead.data_ptr(), ld, acts.dhead.data_ptr() + 4, ld
+    return acts.dv.data_ptr(), 1, acts.dmean.data_ptr(), acts.dmean.shape[1]
+
+
+def backward(policy, acts, gflat, keep=False):
+    """Parameter gradients of one batch into the flat gradient buffer `gflat` (overwrites, never
+    accumulates).  With keep=True the pre-activation gradients of every layer stay on `acts`
+    (dy1, dy2, dy3, dfeat / dhc*, dha*) -- the `grad_output`s KFAC's backward hooks would see."""
+    gv = lambda p: policy.grad_view(p, gflat)
+    if acts.cnn:
+        L = cnn_layer_params(policy)
+        wh, _ = head_views(policy, policy.flat_params)
+        gwh, gbh = head_views(policy, gflat)
+        ops.linear_wgrad(acts.dhead, acts.feat, gwh, gbh)
+        dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
+        ops.linear_wgrad(dfeat, acts.flat3, gv(L['fc'][0]), gv(L['fc'][1]).view(-1))
+        dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
+        w3, w2, w1 = L['conv3'][0], L['conv2'][0], L['conv1'][0]
+        ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
+        dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1)
+        ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1))
+        dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2)
+        ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1), in_scale=1.0 / 255.0,
+                         gather_idx=acts.idx)
+        if keep:
+            acts.dfeat, acts.dy3, acts.dy2, acts.dy1 = dfeat, dy3, dy2, dy1
+        return
+    L = mlp_layer_params(policy)
+    # critic tower
+    ops.linear_wgrad(acts.dv, acts.hc2, gv(L['critic'][0]), gv(L['critic'][1]).view(-1))
+    dhc2 = ops.linear_dgrad(acts.dv, L['critic'][0], gate_src=acts.hc2, gate='tanh')
+    ops.linear_wgrad(dhc2, acts.hc1, gv(L['c2'][0]), gv(L['c2'][1]).view(-1))
+    dhc1 = ops.linear_dgrad(dhc2, L['c2'][0], gate_src=acts.hc1, gate='tanh')
+    ops.linear_wgrad(dhc1, acts.obs, gv(L['c0'][0]), gv(L['c0'][1]).view(-1))
+    # actor tower
+    ops.linear_wgrad(acts.dmean, acts.ha2, gv(L['mean'][0]), gv(L['mean'][1]).view(-1))
+    dha2 = ops.linear_dgrad(acts.dmean, L['mean'][0], gate_src=acts.ha2, gate='tanh')
+    ops.linear_wgrad(dha2, acts.ha1, gv(L['a2'][0]), gv(L['a2'][1]).view(-1))
+    dha1 = ops.linear_dgrad(dha2, L['a2'][0], gate_src=acts.ha1, gate='tanh')
+    ops.linear_wgrad(dha1, acts.obs, gv(L['a0'][0]), gv(L['a0'][1]).view(-1))
+    if keep:
+        acts.dhc2, acts.dhc1, acts.dha2, acts.dha1 = dhc2, dhc1, dha2, dha1
+
+
+# ----------------------------------------------------------------------------------------------
+# fused loss + backward seeds (csrc/loss.hip)
+# ----------------------------------------------------------------------------------------------
+ALGO_PPO, ALGO_A2C, ALGO_FISHER = 0, 1, 2
+
+
+def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, old_values=None, returns=None,
+                adv=None, gather_idx=None, clip=0.0, value_coef=0.0, entropy_coef=0.0, use_clipped_value_loss=True,
+                gflat=None, logp_out=None):
+    """Launch the fused loss kernel; fills the seed buffers on `acts` (and d logstd into `gflat`)."""
+    dev = acts.head.device if acts.cnn else acts.v.device
+    L = _hip.lib()
+    B = acts.head.shape[0] if acts.cnn else acts.v.shape[0]
+    A = policy.dist.num_outputs
+    new_seed_buffers(policy, acts)
+    args = _hip.LossArgs()
+    args.algo, args.dist, args.B, args.A = algo, policy.dist.kind, B, A
+    vp, vld = acts.value_ptr_ld()
+    dp, dld = acts.dist_ptr_ld()
+    args.values, args.ld_values, args.dist_in, args.ld_dist = vp, vld, dp, dld
+    p = lambda t, dt=f32, name='loss operand': (None if t is None else _hip.dev_ptr(t, dt, name).value)
+    if policy.dist.kind == 1:
+        ls = logstd_param(policy)
+        args.logstd = p(ls.detach())
+        args.dlogstd = p(policy.grad_view(ls, policy.flat_grads if gflat is None else gflat))
+        args.actions = p(actions, f32, 'actions')
+    else:
+        args.actions = p(actions, torch.int64, 'actions')
+    args.old_logp, args.old_values, args.returns, args.adv = p(old_logp), p(old_values), p(returns), p(adv)
+    args.gather_idx = p(gather_idx, torch.int64, 'gather_idx')
+    args.clip, args.value_coef, args.entropy_coef, args.inv_batch = clip, value_coef, entropy_coef, inv_batch
+    args.use_clipped_value_loss = 1 if use_clipped_value_loss else 0
+    dvp, dvld, ddp, ddld = seed_ptrs(acts)
+    args.dvalues, args.ld_dvalues, args.ddist, args.ld_ddist = dvp, dvld, ddp, ddld
+    args.logp_out = p(logp_out)
+    args.loss_acc = p(loss_acc)
+    ws = ops.workspace(dev, L.acktr_policy_loss_workspace_bytes(B, A), 'loss')
+    args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    rc = L.acktr_policy_loss_f32(ctypes.byref(args), _hip.cur_stream(dev))
+    _hip.check(rc, 'acktr_policy_loss_f32')
+
+
+# ----------------------------------------------------------------------------------------------
+# autograd bridge for Policy.evaluate_actions (model.py:72-79)
+# ----------------------------------------------------------------------------------------------
+class EvalActions(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, policy, inputs, action, *params):
+        acts = forward(policy, inputs)
+        B = inputs.shape[0]
+        A = policy.dist.num_outputs
+        dev = inputs.device
+        L = _hip.lib()
+        logp = torch.empty(B, 1, dtype=f32, device=dev)
+        ent = torch.empty(B, dtype=f32, device=dev)
+        kind = policy.dist.kind
+        act = action.contiguous()
+        if kind == 0:
+            act = act.long().view(-1)
+        else:
+            act = act.to(f32)
+        ls = logstd_param(policy).detach() if kind == 1 else None
+        dp, dld = acts.dist_ptr_ld()
+        rc = L.acktr_dist_fwd_f32(kind, dp, dld, _hip.dev_ptr(ls), _hip.dev_ptr(act), B, A, _hip.dev_ptr(logp),
+                                  _hip.dev_ptr(ent), _hip.cur_stream(dev))
+        _hip.check(rc, 'acktr_dist_fwd_f32')
+        ctx.policy, ctx.acts, ctx.act = policy, acts, act
+        ctx.nparams = len(params)
+        return acts.value().clone(), logp, ent.mean()
+
+    @staticmethod
+    def backward(ctx, dvalue, dlogp, dent):
+        policy, acts, act = ctx.policy, ctx.acts, ctx.act
+        B = act.shape[0]
+        A = policy.dist.num_outputs
+        kind = policy.dist.kind
+        dev = act.device
+        L = _hip.lib()
+        new_seed_buffers(policy, acts)
+        gflat = torch.zeros_like(policy.flat_params)
+        dvp, dvld, ddp, ddld = seed_ptrs(acts)
+        if acts.cnn:
+            acts.dhead[:, 0:1].copy_(dvalue)
+        else:
+            acts.dv.copy_(dvalue)
+        dl = dlogp.contiguous().view(-1)
+        de = (dent / B).expand(B).contiguous()
+        ls = logstd_param(policy) if kind == 1 else None
+        ws = ops.workspace(dev, L.acktr_policy_loss_workspace_bytes(B, A), 'loss')
+        dp, dld = acts.dist_ptr_ld()
+        rc = L.acktr_dist_bwd_f32(kind, dp, dld, _hip.dev_ptr(ls.detach() if ls is not None else None),
+                                  _hip.dev_ptr(act), _hip.dev_ptr(dl), _hip.dev_ptr(de), B, A, ddp, ddld,
+                                  _hip.dev_ptr(policy.grad_view(ls, gflat) if ls is not None else None),
+                                  _hip.dev_ptr(ws), ws.numel(), _hip.cur_stream(dev))
+        _hip.check(rc, 'acktr_dist_bwd_f32')
+        backward(policy, acts, gflat)
+        grads = tuple(policy.grad_view(p, gflat) for p in policy.parameters())
+        assert len(grads) == ctx.nparams
+        return (None, None, None) + grads

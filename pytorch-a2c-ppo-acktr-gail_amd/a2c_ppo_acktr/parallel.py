@@ -1,0 +1,47 @@
+"""Data-parallel sharding of the update path: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).  New in this build -- the reference is single device (main.py:39).
+
+Scheme: the rollout storage is replicated; every rank draws the SAME minibatch permutation
+(CPU generator, same seed) and takes a contiguous slice of each minibatch.  Per-sample loss terms are
+scaled by 1/B_global, so a SUM all-reduce of the flat gradient bucket (one 3.47 MB message for NatureCNN)
+yields exactly the full-minibatch gradient; clip-norm + optimiser then run replicated on identical data,
+so parameters never need a broadcast.
+"""
+import torch
+import torch.distributed as dist
+
+
+class DataParallel(object):
+    def __init__(self, group=None):
+        self.group = group
+        if dist.is_available() and dist.is_initialized():
+            self.world = dist.get_world_size(group)
+            self.rank = dist.get_rank(group)
+        else:
+            self.world, self.rank = 1, 0
+
+    @property
+    def active(self):
+        return self.world > 1
+
+    def bounds(self, n):
+        """Contiguous balanced split of n items: [lo, hi) of this rank."""
+        return (n * self.rank) // self.world, (n * (self.rank + 1)) // self.world
+
+    def shard(self, idx):
+        """This rank's slice of a minibatch index tensor."""
+        if not self.active:
+            return idx
+        lo, hi = self.bounds(idx.numel())
+        return idx[lo:hi]
+
+    def all_reduce_sum_(self, flat):
+        """In-place SUM all-reduce of one flat bucket (gradients, KFAC factors, loss accumulators)."""
+        if self.active:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        return flat
+
+    def broadcast_(self, t, src):
+        if self.active:
+            dist.broadcast(t, src=src, group=self.group)
+        return t

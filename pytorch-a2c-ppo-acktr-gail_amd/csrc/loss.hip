@@ -1,0 +1,316 @@
+// Action distributions (log-prob / entropy, forward + backward) and the fused PPO / A2C / ACKTR-Fisher
+// loss kernels.  One lane per sample; the rollout-side operands (actions, old log-probs, old values,
+// returns, advantages) are read THROUGH the minibatch index, so storage.py:127-140's seven gathers
+// never materialise.  Loss sums are reduced block-wise into fixed-order partials (deterministic).
+//
+// Reference arithmetic restated here:
+//   distributions.py:18-29  + torch/distributions/categorical.py:78,150-162   (Categorical)
+//   distributions.py:36-41,86-95 + torch/distributions/normal.py:88-103,115-116 (DiagGaussian)
+//   algo/ppo.py:61-81, algo/a2c_acktr.py:48-51,56-65,71-72 (losses; backward = what autograd derives,
+//   including torch's "ties split the gradient" rule of minimum / maximum)
+#include "common.hpp"
+#include "../../include/acktr_hip.h"
+
+namespace acktr {
+
+constexpr int LOSS_THREADS = 256;
+constexpr float HALF_LOG_2PI = 0.91893853320467274178f;   // log(sqrt(2*pi))
+
+struct DistEval {
+    float logp, ent;
+};
+
+// ---- categorical -------------------------------------------------------------------------
+__device__ __forceinline__ DistEval categorical_eval(const float* z, int A, long a, float* lse_out) {
+    float m = z[0];
+    for (int i = 1; i < A; ++i) m = fmaxf(m, z[i]);
+    float s = 0.f;
+    for (int i = 0; i < A; ++i) s += expf(z[i] - m);
+    const float lse = m + logf(s);
+    float ent = 0.f;
+    for (int i = 0; i < A; ++i) {
+        const float lp = fmaxf(z[i] - lse, -3.402823466e+38f);   // clamp(logits, min=finfo.min)
+        ent -= lp * expf(lp);
+    }
+    DistEval r;
+    r.logp = (a >= 0 && a < A) ? z[a] - lse : 0.f;
+    r.ent = ent;
+    *lse_out = lse;
+    return r;
+}
+// dz_i = dlogp*(delta_ia - p_i) - dent*p_i*(logp_i + H)
+__device__ __forceinline__ void categorical_bwd(const float* z, int A, long a, float lse, float ent, float dlogp,
+                                                float dent, float* dz) {
+    for (int i = 0; i < A; ++i) {
+        const float lp = z[i] - lse, p = expf(lp);
+        dz[i] = dlogp * ((i == a ? 1.f : 0.f) - p) - dent * p * (lp + ent);
+    }
+}
+
+// ---- diagonal gaussian -------------------------------------------------------------------
+__device__ __forceinline__ DistEval gaussian_eval(const float* mu, const float* logstd, const float* act, int A) {
+    DistEval r;
+    r.logp = 0.f;
+    r.ent = 0.f;
+    for (int j = 0; j < A; ++j) {
+        const float sd = expf(logstd[j]);
+        const float var = sd * sd, ls = logf(sd), d = act[j] - mu[j];
+        r.logp += -(d * d) / (2.f * var) - ls - HALF_LOG_2PI;
+        r.ent += 0.5f + HALF_LOG_2PI + ls;
+    }
+    return r;
+}
+
+struct LossTerms {
+    float dlogp, dv, vl, al;
+};
+
+// PPO: ppo.py:61-77 and its autograd backward.  Returns the SUMMANDS (not yet divided by B).
+__device__ __forceinline__ LossTerms ppo_terms(float logp, float v, float old_logp, float old_v, float ret, float adv,
+                                               float clip, int clipped_vl) {
+    LossTerms t;
+    const float ratio = expf(logp - old_logp);
+    const float lo = 1.0f - clip, hi = 1.0f + clip;
+    const float rc = fminf(fmaxf(ratio, lo), hi);
+    const float s1 = ratio * adv, s2 = rc * adv;
+    t.al = -fminf(s1, s2);
+    const float inr = (ratio >= lo && ratio <= hi) ? 1.f : 0.f;
+    float g1, g2;   // d min(s1,s2) / d s1, / d s2   (ties split, torch minimum backward)
+    if (s1 < s2) { g1 = 1.f; g2 = 0.f; }
+    else if (s1 > s2) { g1 = 0.f; g2 = 1.f; }
+    else { g1 = 0.5f; g2 = 0.5f; }
+    t.dlogp = -(g1 * adv + g2 * adv * inr) * ratio;
+    const float e = v - ret;
+    if (clipped_vl) {
+        const float dvv = v - old_v;
+        const float vpc = old_v + fminf(fmaxf(dvv, -clip), clip);
+        const float ec = vpc - ret;
+        const float vl = e * e, vlc = ec * ec;
+        const float inv = (dvv >= -clip && dvv <= clip) ? 1.f : 0.f;
+        float h1, h2;   // torch maximum backward
+        if (vl > vlc) { h1 = 1.f; h2 = 0.f; }
+        else if (vl < vlc) { h1 = 0.f; h2 = 1.f; }
+        else { h1 = 0.5f; h2 = 0.5f; }
+        t.vl = 0.5f * fmaxf(vl, vlc);
+        t.dv = 0.5f * (h1 * 2.f * e + h2 * 2.f * ec * inv);
+    } else {
+        t.vl = 0.5f * e * e;
+        t.dv = e;
+    }
+    return t;
+}
+
+// One kernel for all (algo, dist) pairs.  algo: 0 PPO, 1 A2C, 2 ACKTR Fisher.
+template <int DIST>
+__global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_args a, float* partial) {
+    __shared__ float sm[16];
+    const int b = blockIdx.x * LOSS_THREADS + threadIdx.x;
+    const int A = a.A;
+    float vl = 0.f, al = 0.f, en = 0.f;
+    const int NP = 3 + (DIST == 1 ? A : 0);
+    float dls[DIST == 1 ? 16 : 1];
+    if (DIST == 1) for (int j = 0; j < 16; ++j) dls[j] = 0.f;
+    if (b < a.B) {
+        const long src = a.gather_idx ? (long)a.gather_idx[b] : (long)b;
+        const float v = a.values[(long)b * a.ld_values];
+        const float* din = a.dist_in + (long)b * a.ld_dist;
+        float lse = 0.f;
+        long act_i = 0;
+        const float* act_f = nullptr;
+        DistEval d;
+        if (DIST == 0) {
+            act_i = ((const int64_t*)a.actions)[src];
+            d = categorical_eval(din, A, act_i, &lse);
+        } else {
+            act_f = (const float*)a.actions + src * A;
+            d = gaussian_eval(din, a.logstd, act_f, A);
+        }
+        if (a.logp_out) a.logp_out[b] = d.logp;
+        float dlogp, dv;
+        if (a.algo == 0) {
+            const LossTerms t = ppo_terms(d.logp, v, a.old_logp[src], a.old_values[src], a.returns[src], a.adv[src],
+                                          a.clip, a.use_clipped_value_loss);
+            vl = t.vl; al = t.al;
+            dlogp = t.dlogp * a.inv_batch;
+            dv = a.value_coef * t.dv * a.inv_batch;
+        } else if (a.algo == 1) {         // a2c_acktr.py:48-51: adv = R - v; VL = mean(adv^2); AL = -mean(adv.detach()*logp)
+            const float adv = a.returns[src] - v;
+            vl = adv * adv; al = -(adv * d.logp);
+            dlogp = -adv * a.inv_batch;
+            dv = a.value_coef * (-2.f * adv) * a.inv_batch;
+        } else {                          // a2c_acktr.py:56-65: pg_fisher = -mean(logp); vf_fisher = -mean((v-(v+noise))^2)
+            const float sample = v + a.adv[src];      // `adv` carries the CPU-drawn noise (F7)
+            const float diff = v - sample;
+            vl = -(diff * diff); al = -d.logp;
+            dlogp = -a.inv_batch;
+            dv = -2.f * diff * a.inv_batch;
+        }
+        en = d.ent;
+        // entropy enters the loss as  -entropy_coef * mean(entropy)   (not in the Fisher loss)
+        const float dent = (a.algo == 2) ? 0.f : -a.entropy_coef * a.inv_batch;
+        if (a.dvalues) a.dvalues[(long)b * a.ld_dvalues] = dv;
+        float* dd = a.ddist + (long)b * a.ld_ddist;
+        if (DIST == 0) {
+            categorical_bwd(din, A, act_i, lse, d.ent, dlogp, dent, dd);
+        } else {
+            for (int j = 0; j < A; ++j) {
+                const float sd = expf(a.logstd[j]);
+                const float var = sd * sd, dj = act_f[j] - din[j];
+                dd[j] = dlogp * dj / var;
+                dls[j] = dlogp * (dj * dj / var - 1.f) + dent;
+            }
+        }
+    }
+    float* out = partial + (long)blockIdx.x * NP;
+    float r;
+    r = block_sum(vl, sm); if (threadIdx.x == 0) out[0] = r;
+    r = block_sum(al, sm); if (threadIdx.x == 0) out[1] = r;
+    r = block_sum(en, sm); if (threadIdx.x == 0) out[2] = r;
+    if (DIST == 1)
+        for (int j = 0; j < A; ++j) {
+            r = block_sum(dls[j], sm);
+            if (threadIdx.x == 0) out[3 + j] = r;
+        }
+}
+
+// fixed-order final reduction: loss_acc[0..2] += mean terms; dlogstd[j] = sum
+__global__ __launch_bounds__(64) void policy_loss_finalize_kernel(const float* partial, int nblk, int NP, float inv_batch,
+                                                                  float* loss_acc, float* dlogstd) {
+    const int j = threadIdx.x;
+    if (j >= NP) return;
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += partial[(long)i * NP + j];
+    if (j < 3) { if (loss_acc) loss_acc[j] += s * inv_batch; }
+    else if (dlogstd) dlogstd[j - 3] = s;
+}
+
+// ---- stand-alone distribution kernels (autograd path of Policy.evaluate_actions) ----------
+template <int DIST>
+__global__ __launch_bounds__(LOSS_THREADS) void dist_fwd_kernel(const float* dist_in, long ld, const float* logstd,
+                                                                const void* actions, int B, int A, float* logp,
+                                                                float* entropy) {
+    const int b = blockIdx.x * LOSS_THREADS + threadIdx.x;
+    if (b >= B) return;
+    DistEval d;
+    if (DIST == 0) {
+        float lse;
+        d = categorical_eval(dist_in + (long)b * ld, A, ((const int64_t*)actions)[b], &lse);
+    } else {
+        d = gaussian_eval(dist_in + (long)b * ld, logstd, (const float*)actions + (long)b * A, A);
+    }
+    logp[b] = d.logp;
+    entropy[b] = d.ent;
+}
+
+template <int DIST>
+__global__ __launch_bounds__(LOSS_THREADS) void dist_bwd_kernel(const float* dist_in, long ld, const float* logstd,
+                                                                const void* actions, const float* dlogp,
+                                                                const float* dent, int B, int A, float* ddist, long ldd,
+                                                                float* partial) {
+    __shared__ float sm[16];
+    const int b = blockIdx.x * LOSS_THREADS + threadIdx.x;
+    float dls[DIST == 1 ? 16 : 1];
+    if (DIST == 1) for (int j = 0; j < 16; ++j) dls[j] = 0.f;
+    if (b < B) {
+        const float* din = dist_in + (long)b * ld;
+        float* dd = ddist + (long)b * ldd;
+        const float gl = dlogp ? dlogp[b] : 0.f, ge = dent ? dent[b] : 0.f;
+        if (DIST == 0) {
+            float lse;
+            const long act = ((const int64_t*)actions)[b];
+            const DistEval d = categorical_eval(din, A, act, &lse);
+            categorical_bwd(din, A, act, lse, d.ent, gl, ge, dd);
+        } else {
+            const float* act = (const float*)actions + (long)b * A;
+            for (int j = 0; j < A; ++j) {
+                const float sd = expf(logstd[j]);
+                const float var = sd * sd, dj = act[j] - din[j];
+                dd[j] = gl * dj / var;
+                dls[j] = gl * (dj * dj / var - 1.f) + ge;
+            }
+        }
+    }
+    if (DIST == 1)
+        for (int j = 0; j < A; ++j) {
+            const float r = block_sum(dls[j], sm);
+            if (threadIdx.x == 0) partial[(long)blockIdx.x * (3 + A) + 3 + j] = r;
+        }
+}
+
+}  // namespace acktr
+
+using namespace acktr;
+
+extern "C" long acktr_policy_loss_workspace_bytes(int B, int A) {
+    return (long)cdiv(B, LOSS_THREADS) * (3 + A) * (long)sizeof(float) + 256;
+}
+
+extern "C" int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream) {
+    ACKTR_ARG(args, "policy_loss: null args");
+    const acktr_loss_args& a = *args;
+    ACKTR_ARG(a.algo >= 0 && a.algo <= 2 && (a.dist == 0 || a.dist == 1), "policy_loss: bad algo/dist");
+    ACKTR_ARG(a.B > 0 && a.A > 0, "policy_loss: bad sizes B=%d A=%d", a.B, a.A);
+    ACKTR_ARG(a.dist == 0 || a.A <= 16, "policy_loss: gaussian action dim %d > 16 unsupported", a.A);
+    ACKTR_ARG(a.values && a.dist_in && a.actions && a.ddist, "policy_loss: null tensor");
+    ACKTR_ARG(a.dist == 0 || (a.logstd && a.dlogstd), "policy_loss: gaussian needs logstd/dlogstd");
+    ACKTR_ARG(a.algo != 0 || (a.old_logp && a.old_values && a.returns && a.adv), "policy_loss: PPO needs rollout arrays");
+    ACKTR_ARG(a.algo != 1 || a.returns, "policy_loss: A2C needs returns");
+    ACKTR_ARG(a.algo != 2 || a.adv, "policy_loss: Fisher loss needs the noise tensor in `adv`");
+    ACKTR_ARG(a.workspace && a.workspace_bytes >= acktr_policy_loss_workspace_bytes(a.B, a.A),
+              "policy_loss: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = cdiv(a.B, LOSS_THREADS);
+    float* partial = (float*)a.workspace;
+    if (a.dist == 0)
+        hipLaunchKernelGGL((policy_loss_kernel<0>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial);
+    else
+        hipLaunchKernelGGL((policy_loss_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial);
+    ACKTR_LAUNCH_CHECK();
+    const int NP = 3 + (a.dist == 1 ? a.A : 0);
+    hipLaunchKernelGGL(policy_loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nblk, NP, a.inv_batch, a.loss_acc,
+                       a.dist == 1 ? a.dlogstd : (float*)nullptr);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions,
+                                  int B, int A, float* logp, float* entropy, void* stream) {
+    ACKTR_ARG(dist_in && actions && logp && entropy, "dist_fwd: null pointer");
+    ACKTR_ARG(B > 0 && A > 0 && ld >= A, "dist_fwd: bad sizes");
+    ACKTR_ARG(dist == 0 || (dist == 1 && logstd && A <= 16), "dist_fwd: bad distribution arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = cdiv(B, LOSS_THREADS);
+    if (dist == 0)
+        hipLaunchKernelGGL((dist_fwd_kernel<0>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, B, A,
+                           logp, entropy);
+    else
+        hipLaunchKernelGGL((dist_fwd_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, B, A,
+                           logp, entropy);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions,
+                                  const float* dlogp, const float* dentropy, int B, int A, float* ddist, long ldd,
+                                  float* dlogstd, void* workspace, long workspace_bytes, void* stream) {
+    ACKTR_ARG(dist_in && actions && ddist, "dist_bwd: null pointer");
+    ACKTR_ARG(B > 0 && A > 0 && ld >= A && ldd >= A, "dist_bwd: bad sizes");
+    ACKTR_ARG(dist == 0 || (dist == 1 && logstd && dlogstd && A <= 16), "dist_bwd: bad distribution arguments");
+    ACKTR_ARG(dist == 0 || (workspace && workspace_bytes >= acktr_policy_loss_workspace_bytes(B, A)),
+              "dist_bwd: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = cdiv(B, LOSS_THREADS);
+    if (dist == 0) {
+        hipLaunchKernelGGL((dist_bwd_kernel<0>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, dlogp,
+                           dentropy, B, A, ddist, ldd, (float*)workspace);
+        ACKTR_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL((dist_bwd_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, dlogp,
+                           dentropy, B, A, ddist, ldd, (float*)workspace);
+        ACKTR_LAUNCH_CHECK();
+        hipLaunchKernelGGL(policy_loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, nblk, 3 + A, 0.f,
+                           (float*)nullptr, dlogstd);
+        ACKTR_LAUNCH_CHECK();
+    }
+    return 0;
+}

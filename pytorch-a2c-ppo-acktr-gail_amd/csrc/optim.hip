@@ -1,0 +1,154 @@
+// Flat-buffer optimiser kernels: global-norm clip fused with Adam / RMSprop, SGD-momentum for KFAC.
+// All parameters (and grads, and optimiser state) of a Policy live in ONE contiguous fp32 buffer each,
+// so the reference's per-tensor loops (clip_grad_norm_ + optimizer.step, ~100 tiny launches) are two
+// launches here: (1) block partials of sum g^2 in fp64, (2) fixed-order re-reduction + the update.
+//
+// Reference arithmetic restated:
+//   torch/nn/utils/clip_grad.py:102-108,165-169  coef = min(1, max_norm / (||g||_2 + 1e-6))
+//   torch/optim/adam.py:457,476,529-547          single-tensor Adam
+//   torch/optim/rmsprop.py:316-339               single-tensor RMSprop (not centred, no momentum)
+//   torch/optim/sgd.py:358-380                   SGD with momentum (first step: buf = grad)
+#include "common.hpp"
+#include "../../include/acktr_hip.h"
+
+namespace acktr {
+
+constexpr int OPT_THREADS = 256;
+constexpr int OPT_MAX_PARTIALS = 1024;
+
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const float* g, long n, double* partial) {
+    __shared__ double sm[16];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
+        const double x = (double)g[i];
+        s += x * x;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// clip coefficient from the partials (every block recomputes it in the same fixed order)
+__device__ __forceinline__ float clip_coef_from(const double* partial, int nparts, float max_norm, float* sm2,
+                                                float* norm_out) {
+    if (threadIdx.x < 64) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 64) s += partial[i];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) {
+            const float total = (float)sqrt(s);
+            float c = max_norm / (total + 1e-6f);
+            sm2[0] = c > 1.0f ? 1.0f : c;
+            if (norm_out && blockIdx.x == 0) *norm_out = total;
+        }
+    }
+    __syncthreads();
+    return sm2[0];
+}
+
+// mode 0: Adam, 1: RMSprop.  use_clip: multiply the gradient by the clip coefficient first (and write it back,
+// as clip_grad_norm_ does in place).
+template <int MODE>
+__global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, float* g, float* s1, float* s2, long n,
+                                                                  const double* partial, int nparts, int use_clip,
+                                                                  float max_norm, float lr_or_step, float beta1,
+                                                                  float beta2, float eps, float bc2_sqrt,
+                                                                  float* norm_out) {
+    __shared__ float sm2[2];
+    float coef = 1.0f;
+    if (use_clip) coef = clip_coef_from(partial, nparts, max_norm, sm2, norm_out);
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
+        float gi = g[i];
+        if (use_clip) { gi = gi * coef; g[i] = gi; }
+        if (MODE == 0) {
+            float m = s1[i], v = s2[i];
+            m = m + (1.0f - beta1) * (gi - m);                       // exp_avg.lerp_(grad, 1-beta1)
+            v = v * beta2 + (1.0f - beta2) * gi * gi;                // mul_(beta2).addcmul_(g, g, 1-beta2)
+            const float denom = sqrtf(v) / bc2_sqrt + eps;
+            p[i] = p[i] - lr_or_step * (m / denom);                  // addcdiv_(exp_avg, denom, -step_size)
+            s1[i] = m; s2[i] = v;
+        } else {
+            float sq = s1[i];
+            sq = sq * beta2 + (1.0f - beta2) * gi * gi;              // square_avg.mul_(alpha).addcmul_(g, g, 1-alpha)
+            const float avg = sqrtf(sq) + eps;
+            p[i] = p[i] - lr_or_step * (gi / avg);                   // addcdiv_(grad, avg, -lr)
+            s1[i] = sq;
+        }
+    }
+}
+
+// grad *= scale (device scalar, optional) ; SGD momentum: buf = first ? g : mom*buf + g ; p -= lr*buf
+__global__ __launch_bounds__(OPT_THREADS) void sgd_momentum_kernel(float* p, float* g, float* buf, long n,
+                                                                   const float* grad_scale, float lr, float momentum,
+                                                                   int first) {
+    const float sc = grad_scale ? *grad_scale : 1.0f;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
+        float gi = g[i];
+        if (grad_scale) { gi = gi * sc; g[i] = gi; }
+        float b;
+        if (first) b = gi;
+        else b = buf[i] * momentum + gi;
+        buf[i] = b;
+        p[i] = p[i] - lr * b;
+    }
+}
+
+static int grid_for(long n) {
+    int b = cdiv(n, OPT_THREADS * 4);
+    if (b > OPT_MAX_PARTIALS) b = OPT_MAX_PARTIALS;
+    if (b < 1) b = 1;
+    return b;
+}
+}  // namespace acktr
+
+using namespace acktr;
+
+extern "C" long acktr_optim_workspace_bytes(void) { return (long)OPT_MAX_PARTIALS * (long)sizeof(double); }
+
+extern "C" int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                   float max_grad_norm, float step_size, float beta1, float beta2, float eps,
+                                   float bias_correction2_sqrt, float* total_norm_out, void* workspace, void* stream) {
+    ACKTR_ARG(params && grads && exp_avg && exp_avg_sq && workspace, "clip_adam: null pointer");
+    ACKTR_ARG(n > 0, "clip_adam: n must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const int use_clip = max_grad_norm > 0.f;
+    const int nb = grid_for(n);
+    if (use_clip) {
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace);
+        ACKTR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
+                       (const double*)workspace, nb, use_clip, max_grad_norm, step_size, beta1, beta2, eps,
+                       bias_correction2_sqrt, total_norm_out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_clip_rmsprop_f32(float* params, float* grads, float* square_avg, long n, float max_grad_norm,
+                                      float lr, float alpha, float eps, float* total_norm_out, void* workspace,
+                                      void* stream) {
+    ACKTR_ARG(params && grads && square_avg && workspace, "clip_rmsprop: null pointer");
+    ACKTR_ARG(n > 0, "clip_rmsprop: n must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const int use_clip = max_grad_norm > 0.f;
+    const int nb = grid_for(n);
+    if (use_clip) {
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace);
+        ACKTR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((clip_update_kernel<1>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, square_avg,
+                       (float*)nullptr, n, (const double*)workspace, nb, use_clip, max_grad_norm, lr, 0.f, alpha, eps, 1.f,
+                       total_norm_out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_sgd_momentum_f32(float* params, float* grads, float* momentum_buf, long n,
+                                      const float* grad_scale_dev, float lr, float momentum, int first_step,
+                                      void* stream) {
+    ACKTR_ARG(params && grads && momentum_buf, "sgd_momentum: null pointer");
+    ACKTR_ARG(n > 0, "sgd_momentum: n must be positive");
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n)), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grads,
+                       momentum_buf, n, grad_scale_dev, lr, momentum, first_step);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,158 @@
+"""GPU parity of Policy.evaluate_actions, PPO.update and A2C update (HIP path through the C-ABI)
+against goldens produced by the reference itself (tests/golden/make_golden.py).
+Tolerance: BASELINE.json north_star -- losses and gradients within 1e-4 relative."""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import (A2C_CASES, A2C_HP, EVAL_CASES, PPO_CASES, check_summary, eval_case_inputs, golden, shapes_for, t)
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+class Discrete(object):
+    def __init__(self, n):
+        self.n = n
+
+
+class Box(object):
+    def __init__(self, d):
+        self.shape = (d,)
+
+
+def make_policy(kind, od, A, salt):
+    from a2c_ppo_acktr.model import Policy
+    if kind == 'cnn':
+        pol = Policy((4, 84, 84), Discrete(A))
+    else:
+        pol = Policy((od,), Box(A))
+    P = synth.make_params(shapes_for(kind, od, A), salt)
+    pol.load_state_dict(OrderedDict((k, t(v)) for k, v in P.items()), strict=True)
+    pol.to('cuda')
+    return pol
+
+
+def close(a, b, tol=TOL):
+    return abs(a - b) <= tol * max(abs(b), 1e-3)
+
+
+@pytest.mark.parametrize('ci', range(len(EVAL_CASES)))
+def test_evaluate_actions_autograd_path(ci):
+    """The drop-in API exactly as user code would drive it: evaluate_actions -> torch loss -> .backward()."""
+    tag, kind, od, A, B, clip, c_e = EVAL_CASES[ci]
+    G = golden('eval')
+    pol = make_policy(kind, od, A, 40 + ci)
+    x = {k: t(v).cuda() for k, v in eval_case_inputs(tag, kind, od, A, B, ci).items()}
+    olp = t(G[tag + '/old_logp']).cuda()
+    values, logp, ent, _ = pol.evaluate_actions(x['obs'], None, None, x['act'])
+    np.testing.assert_allclose(values.detach().cpu().numpy(), G[tag + '/values'], rtol=TOL, atol=2e-5)
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), G[tag + '/logp'], rtol=TOL, atol=2e-5)
+    assert close(ent.item(), float(G[tag + '/entropy']))
+    ratio = torch.exp(logp - olp)
+    surr1 = ratio * x['adv']
+    surr2 = torch.clamp(ratio, 1.0 - clip, 1.0 + clip) * x['adv']
+    action_loss = -torch.min(surr1, surr2).mean()
+    vpc = x['vp'] + (values - x['vp']).clamp(-clip, clip)
+    value_loss = 0.5 * torch.max((values - x['ret']).pow(2), (vpc - x['ret']).pow(2)).mean()
+    assert close(value_loss.item(), float(G[tag + '/value_loss']))
+    assert close(action_loss.item(), float(G[tag + '/action_loss']))
+    (value_loss * 0.5 + action_loss - ent * c_e).backward()
+    for n, p in pol.named_parameters():
+        assert p.grad is not None, n
+        check_summary(G, tag + '/grad/' + n, p.grad.cpu().numpy(), TOL, tag)
+
+
+@pytest.mark.parametrize('ci', range(len(EVAL_CASES)))
+def test_fused_loss_path(ci):
+    """engine.forward -> fused PPO loss kernel -> engine.backward (what PPO.update runs)."""
+    from a2c_ppo_acktr import engine
+    tag, kind, od, A, B, clip, c_e = EVAL_CASES[ci]
+    G = golden('eval')
+    pol = make_policy(kind, od, A, 40 + ci)
+    x = {k: t(v).cuda() for k, v in eval_case_inputs(tag, kind, od, A, B, ci).items()}
+    olp = t(G[tag + '/old_logp']).cuda().view(-1)
+    loss_acc = torch.zeros(3, device='cuda')
+    logp = torch.empty(B, device='cuda')
+    with torch.no_grad():
+        acts = engine.forward(pol, x['obs'])
+        act = x['act'].view(-1) if kind == 'cnn' else x['act']
+        engine.policy_loss(pol, acts, engine.ALGO_PPO, act.contiguous(), loss_acc, 1.0 / B, old_logp=olp,
+                           old_values=x['vp'].view(-1), returns=x['ret'].view(-1), adv=x['adv'].view(-1), clip=clip,
+                           value_coef=0.5, entropy_coef=c_e, logp_out=logp)
+        engine.backward(pol, acts, pol.flat_grads)
+    vl, al, en = loss_acc.tolist()
+    assert close(vl, float(G[tag + '/value_loss']))
+    assert close(al, float(G[tag + '/action_loss']))
+    assert close(en, float(G[tag + '/entropy']))
+    np.testing.assert_allclose(logp.cpu().numpy(), G[tag + '/logp'].reshape(-1), rtol=TOL, atol=2e-5)
+    for n, p in pol.named_parameters():
+        check_summary(G, tag + '/grad/' + n, pol.grad_view(p).cpu().numpy(), TOL, tag)
+
+
+def make_storage(ro, obs_shape, space):
+    from a2c_ppo_acktr.storage import RolloutStorage
+    T, N = ro['rewards'].shape[:2]
+    rs = RolloutStorage(T, N, obs_shape, space, 1)
+    for k in ('obs', 'rewards', 'value_preds', 'returns', 'action_log_probs', 'actions', 'masks', 'bad_masks'):
+        getattr(rs, k).copy_(t(ro[k]))
+    rs.to('cuda')
+    return rs
+
+
+@pytest.mark.parametrize('ci', range(len(PPO_CASES)))
+def test_ppo_update_vs_reference(ci):
+    from a2c_ppo_acktr import algo
+    tag, kind, od, A, T, N, hp = PPO_CASES[ci]
+    G = golden('ppo')
+    pol = make_policy(kind, od, A, 60 + ci)
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=700 + ci)
+    vlast = ro['value_preds'][-1].copy()
+    ro['action_log_probs'] = G[tag + '/action_log_probs'].copy()
+    ro['value_preds'] = G[tag + '/value_preds'].copy()
+    ro['value_preds'][-1] = vlast
+    rs = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
+    rs.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
+    agent = algo.PPO(pol, **hp)
+    for it in range(2):
+        torch.manual_seed(4321 + it)
+        res = agent.update(rs)
+        np.testing.assert_allclose(np.array(res), G[tag + '/update%d/losses' % it], rtol=TOL, atol=1e-6)
+        for n, p in pol.named_parameters():
+            check_summary(G, tag + '/update%d/param/%s' % (it, n), p.detach().cpu().numpy(), TOL, tag)
+
+
+@pytest.mark.parametrize('ci', range(len(A2C_CASES)))
+def test_a2c_update_vs_reference(ci):
+    from a2c_ppo_acktr import algo
+    tag, kind, od, A, T, N = A2C_CASES[ci]
+    G = golden('a2c')
+    pol = make_policy(kind, od, A, 80 + ci)
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=800 + ci)
+    rs = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
+    rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
+    agent = algo.A2C_ACKTR(pol, acktr=False, **A2C_HP)
+    for it in range(3):
+        res = agent.update(rs)
+        np.testing.assert_allclose(np.array(res), G[tag + '/update%d/losses' % it], rtol=TOL, atol=1e-6)
+        for n, p in pol.named_parameters():
+            check_summary(G, tag + '/update%d/param/%s' % (it, n), p.detach().cpu().numpy(), TOL, tag)
+
+
+def test_act_and_get_value_shapes():
+    pol = make_policy('cnn', None, 6, 3)
+    obs = torch.randint(0, 256, (9, 4, 84, 84)).float().cuda()
+    v, a, lp, h = pol.act(obs, None, None)
+    assert v.shape == (9, 1) and a.shape == (9, 1) and lp.shape == (9, 1) and a.dtype == torch.int64
+    v2 = pol.get_value(obs, None, None)
+    assert torch.equal(v, v2)
+    _, a_det, _, _ = pol.act(obs, None, None, deterministic=True)
+    assert a_det.shape == (9, 1)
+    pol2 = make_policy('mlp', 11, 3, 4)
+    v, a, lp, h = pol2.act(torch.randn(5, 11).cuda(), None, None)
+    assert v.shape == (5, 1) and a.shape == (5, 3) and lp.shape == (5, 1)

@@ -70,3 +70,11 @@ A2C_CASES = [('cnn', 'cnn', None, 6, 5, 16), ('mlp', 'mlp', 17, 6, 5, 16)]
 def shapes_for(kind, od, A):
     from oracle import policy_ref
     return policy_ref.cnn_param_shapes(4, 512, A) if kind == 'cnn' else policy_ref.mlp_param_shapes(od, 64, A)
+
+
+def golden_subset(G, prefix, arr):
+    """(golden values, matching entries of arr) for a summarised tensor."""
+    a = np.asarray(arr).reshape(-1)
+    if prefix + '#full' in G.files:
+        return G[prefix + '#full'].astype(np.float64), a.astype(np.float64)
+    return G[prefix + '#sample'].astype(np.float64), a[::SAMPLE_STRIDE].astype(np.float64)

@@ -128,7 +128,14 @@ def test_ppo_update_vs_reference(ci):
 
 @pytest.mark.parametrize('ci', range(len(A2C_CASES)))
 def test_a2c_update_vs_reference(ci):
+    """Losses: 1e-4 vs the reference golden on every update.  Parameters: 1e-4 after the first update.
+    After later updates RMSprop's element-wise normalisation (step ~ lr*g/(0.1|g|+eps) right after
+    initialisation) turns fp32 summation-order noise on small-gradient elements into O(lr) differences, for
+    the reference as much as for us; so there the bar is accuracy against an fp64 run of the same algorithm:
+    our distance to fp64 must not exceed twice the reference's own distance to fp64 (+1e-4)."""
     from a2c_ppo_acktr import algo
+    from helpers import golden_subset, params_torch
+    from oracle import algo_ref, returns_ref
     tag, kind, od, A, T, N = A2C_CASES[ci]
     G = golden('a2c')
     pol = make_policy(kind, od, A, 80 + ci)
@@ -136,12 +143,29 @@ def test_a2c_update_vs_reference(ci):
     ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=800 + ci)
     rs = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
     rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
+    # fp64 truth (oracle algorithm in double precision)
+    P64 = OrderedDict((k, v.double()) for k, v in params_torch(synth.make_params(shapes_for(kind, od, A), 80 + ci)).items())
+    returns_ref.compute_returns(ro['rewards'], ro['value_preds'], ro['returns'], ro['masks'], ro['bad_masks'],
+                                ro['next_value'], False, 0.99, 0.95, False)
+    ro64 = {k: (t(v).double() if v.dtype == np.float32 else t(v)) for k, v in ro.items()}
+    opt64 = algo_ref.rmsprop_init(P64)
     agent = algo.A2C_ACKTR(pol, acktr=False, **A2C_HP)
     for it in range(3):
         res = agent.update(rs)
+        algo_ref.a2c_update(P64, opt64, ro64, **A2C_HP)
         np.testing.assert_allclose(np.array(res), G[tag + '/update%d/losses' % it], rtol=TOL, atol=1e-6)
         for n, p in pol.named_parameters():
-            check_summary(G, tag + '/update%d/param/%s' % (it, n), p.detach().cpu().numpy(), TOL, tag)
+            prefix = tag + '/update%d/param/%s' % (it, n)
+            if it == 0:
+                check_summary(G, prefix, p.detach().cpu().numpy(), TOL, tag)
+            else:
+                gold, mine = golden_subset(G, prefix, p.detach().cpu().numpy())
+                _, truth = golden_subset(G, prefix, P64[n].detach().numpy())
+                nrm = max(np.linalg.norm(truth), 1e-12)
+                e_ref = np.linalg.norm(gold - truth) / nrm
+                e_mine = np.linalg.norm(mine - truth) / nrm
+                assert e_mine <= 2.0 * e_ref + TOL, (prefix, e_mine, e_ref)
+                assert np.linalg.norm(mine - gold) / nrm <= 5e-3, prefix   # sanity bound only
 
 
 def test_act_and_get_value_shapes():

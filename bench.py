@@ -1,0 +1,207 @@
+"""bench.py -- PPO update() throughput of the MI355X-native learner path (NatureCNN 84x84x4).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json configs[2], the configuration the metric "PPO ... update samples/sec (NatureCNN
+84x84x4) at 1/2/4/8 GPU" is quoted on): PPO, 4 epochs x 4 minibatches, T = 128 steps, 32 env processes PER
+GPU (256 processes at 8 GPUs = the top of the config's range), Categorical(6), synthetic uint8-valued frames
+stored as fp32 (F6), clip .1, lr 2.5e-4, entropy .01, GAE.  Weak scaling: per-GPU work is fixed.
+A "step" is one full `PPO.update(rollouts)`; samples per step = T * N_global * ppo_epoch.
+
+One JSON line is printed by rank 0; see DESIGN.md "Measurement" for how each field is derived.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, 'pytorch-a2c-ppo-acktr-gail_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch                                    # noqa: E402
+import torch.distributed as dist                # noqa: E402
+
+T_STEPS, PROCS_PER_GPU, ACTIONS = 128, 32, 6
+PPO_HP = dict(clip_param=0.1, ppo_epoch=4, num_mini_batch=4, value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4,
+              eps=1e-5, max_grad_norm=0.5)
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+FWD_BWD_FLOP_PER_SAMPLE = 39.29e6  # 15.28 fwd + 24.01 bwd MFLOP per sample per minibatch pass
+
+
+class Discrete(object):
+    def __init__(self, n):
+        self.n = n
+
+
+def synth_rollouts(T, N, device, seed):
+    """SURVEY.md 8(d) synthetic inputs, generated on `device` from a fixed seed (identical on every rank)."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    ro = {}
+    ro['obs'] = torch.randint(0, 256, (T + 1, N, 4, 84, 84), device=device, generator=g, dtype=torch.int32).float()
+    ro['rewards'] = torch.randn(T, N, 1, device=device, generator=g)
+    ro['value_preds'] = torch.randn(T + 1, N, 1, device=device, generator=g)
+    ro['action_log_probs'] = 0.1 * torch.randn(T, N, 1, device=device, generator=g) - 1.8
+    ro['actions'] = torch.randint(0, ACTIONS, (T, N, 1), device=device, generator=g)
+    ro['masks'] = (torch.rand(T + 1, N, 1, device=device, generator=g) < 0.99).float()
+    ro['bad_masks'] = (torch.rand(T + 1, N, 1, device=device, generator=g) < 0.995).float()
+    ro['next_value'] = torch.randn(N, 1, device=device, generator=g)
+    return ro
+
+
+def build_agent(device, seed):
+    from a2c_ppo_acktr import algo
+    from a2c_ppo_acktr.model import Policy
+    torch.manual_seed(seed)                       # reference initialisers (orthogonal_) on the CPU generator
+    pol = Policy((4, 84, 84), Discrete(ACTIONS))
+    pol.to(device)
+    return pol, algo.PPO(pol, **PPO_HP)
+
+
+def fill_storage(ro, device):
+    from a2c_ppo_acktr.storage import RolloutStorage
+    T, N = ro['rewards'].shape[:2]
+    rs = RolloutStorage(1, 1, (1,), Discrete(ACTIONS), 1)     # tiny CPU allocation, tensors replaced below
+    rs.num_steps = T
+    for k in ('obs', 'rewards', 'value_preds', 'action_log_probs', 'actions', 'masks', 'bad_masks'):
+        setattr(rs, k, ro[k])
+    rs.returns = torch.zeros(T + 1, N, 1, device=device)
+    rs.recurrent_hidden_states = torch.zeros(T + 1, N, 1, device=device)
+    return rs
+
+
+def cpu_baseline(ro_cpu, seed):
+    """The oracle (CPU restatement of the reference's PPO.update, torch CPU ops) on the per-GPU workload:
+    ONE full update of T=128 x 32 processes, 4 epochs x 4 minibatches (bounded sample, ~10-30 s)."""
+    from collections import OrderedDict
+    from oracle import algo_ref, returns_ref
+    from a2c_ppo_acktr.model import Policy
+    torch.manual_seed(seed)
+    pol = Policy((4, 84, 84), Discrete(ACTIONS))
+    P = OrderedDict((k, v.detach().clone()) for k, v in pol.state_dict().items())
+    ro = {k: v.clone() for k, v in ro_cpu.items()}
+    ro['returns'] = torch.zeros_like(ro['value_preds'])
+    npv = {k: ro[k].numpy() for k in ('rewards', 'value_preds', 'returns', 'masks', 'bad_masks', 'next_value')}
+    returns_ref.compute_returns(npv['rewards'], npv['value_preds'], npv['returns'], npv['masks'], npv['bad_masks'],
+                                npv['next_value'], True, 0.99, 0.95, True)
+    opt = algo_ref.adam_init(P)
+    torch.manual_seed(seed + 1)
+    t0 = time.perf_counter()
+    losses = algo_ref.ppo_update(P, opt, ro, **PPO_HP)
+    dt = time.perf_counter() - t0
+    T, N = ro['rewards'].shape[:2]
+    return dict(value=T * N * PPO_HP['ppo_epoch'] / dt, unit='samples/s', cores=torch.get_num_threads(), kind='port',
+                sample='1 PPO.update of T=%d x N=%d (4 epochs x 4 minibatches of %d) on the host, %.1f s'
+                       % (T, N, T * N // PPO_HP['num_mini_batch'], dt)), losses
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(device)
+
+    from a2c_ppo_acktr import ops
+    N_global = PROCS_PER_GPU * world
+    ro = synth_rollouts(T_STEPS, N_global, device, seed=1234)
+    pol, agent = build_agent(device, seed=7)
+    rs = fill_storage(ro, device)
+    rs.compute_returns(ro['next_value'], True, 0.99, 0.95, True)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    losses = None
+    for i in range(args.warmup):
+        torch.manual_seed(100 + i)
+        losses = agent.update(rs)
+    ops.profiler = {}                    # HIP-event timing of every GEMM-class launch inside the timed region
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        torch.manual_seed(200 + i)
+        losses = agent.update(rs)
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_summary()
+    ops.profiler = None
+    if world > 1:
+        tmax = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    samples_per_step = T_STEPS * N_global * PPO_HP['ppo_epoch']
+    value = samples_per_step * args.steps / dt
+
+    # GAE scan timing (HBM-bound side kernel) on the same storage
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(20):
+        rs.compute_returns(ro['next_value'], True, 0.99, 0.95, True)
+    ev1.record()
+    torch.cuda.synchronize()
+    scan_ms = ev0.elapsed_time(ev1) / 20
+
+    if rank == 0:
+        dom = max(prof.items(), key=lambda kv: kv[1]['total_ms']) if prof else (None, None)
+        gemm_ms = sum(v['total_ms'] for v in prof.values())
+        gemm_flop = sum(v['flops_per_call'] * v['calls'] for v in prof.values())
+        roof = None
+        if dom[0] is not None:
+            ach = dom[1]['flops_per_call'] / (dom[1]['avg_ms'] * 1e-3) / 1e12
+            roof = dict(bound='mfma', kernel=dom[0], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
+                        unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                        avg_launch_ms=round(dom[1]['avg_ms'], 4), flop_per_launch=dom[1]['flops_per_call'])
+        out = dict(metric='PPO update samples/sec (NatureCNN 84x84x4)', value=round(value, 1), unit='samples/s',
+                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='PPO.update NatureCNN 84x84x4 Categorical(6): T=128 x %d procs/GPU (%d global), '
+                                        '4 epochs x 4 minibatches, fp32 MFMA' % (PROCS_PER_GPU, N_global),
+                               global_batch=T_STEPS * N_global, minibatch=T_STEPS * N_global // PPO_HP['num_mini_batch'],
+                               parallelism='dp%d' % world),
+                   roofline=roof,
+                   whole_update=dict(mfma_tflops=round(samples_per_step * args.steps * FWD_BWD_FLOP_PER_SAMPLE / dt / 1e12 / world, 2),
+                                     frac_of_f32_mfma_peak=round(samples_per_step * args.steps * FWD_BWD_FLOP_PER_SAMPLE / dt / 1e12 / world
+                                                                 / MFMA_F32_PEAK_TFLOPS, 4),
+                                     gemm_ops_ms_per_step=round(gemm_ms / args.steps, 3),
+                                     gemm_ops_tflops=round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms else None),
+                   kernels={k: dict(calls=v['calls'], avg_ms=round(v['avg_ms'], 4),
+                                    tflops=round(v['flops_per_call'] / (v['avg_ms'] * 1e-3) / 1e12, 2))
+                            for k, v in sorted(prof.items(), key=lambda kv: -kv[1]['total_ms'])},
+                   gae_scan=dict(T=T_STEPS, N=N_global, ms=round(scan_ms, 4),
+                                 gbps=round(T_STEPS * N_global * 20 / (scan_ms * 1e-3) / 1e9, 2)),
+                   losses=[round(x, 6) for x in losses])
+        if not args.no_cpu_baseline:
+            keep = {k: v[:, :PROCS_PER_GPU].cpu() if v.dim() == 3 or v.dim() == 5 else v[:PROCS_PER_GPU].cpu()
+                    for k, v in ro.items()}
+            cb, _ = cpu_baseline(keep, seed=7)
+            cb['value'] = round(cb['value'], 1)
+            out['cpu_baseline'] = cb
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -11,6 +11,44 @@ from . import _hip
 f32 = torch.float32
 _ws_cache = {}
 
+# Optional per-launch timing with HIP events on the launch stream (used by bench.py for the roofline
+# figures).  `profiler` is None (off) or a dict name -> list of (start_event, end_event, work) tuples.
+profiler = None
+
+
+class _Timed(object):
+    __slots__ = ('name', 'work', 'ev')
+
+    def __init__(self, name, work):
+        self.name, self.work = name, work
+
+    def __enter__(self):
+        if profiler is not None:
+            s = torch.cuda.Event(enable_timing=True)
+            s.record()
+            self.ev = s
+        return self
+
+    def __exit__(self, *a):
+        if profiler is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            profiler.setdefault(self.name, []).append((self.ev, e, self.work))
+        return False
+
+
+def profile_summary():
+    """name -> dict(calls, avg_ms, total_ms, flops_per_call) after a device sync."""
+    out = {}
+    if profiler is None:
+        return out
+    torch.cuda.synchronize()
+    for name, recs in profiler.items():
+        ms = [s.elapsed_time(e) for s, e, _ in recs]
+        out[name] = dict(calls=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms),
+                         flops_per_call=sum(w for _, _, w in recs) / len(recs))
+    return out
+
 
 def workspace(device, nbytes, tag='ws'):
     """Per-(device, tag) scratch buffer, grown on demand and reused across calls."""
@@ -40,9 +78,10 @@ def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out
     if out is None:
         out = torch.empty(B, OC, OH, OW, dtype=f32, device=x.device)
     assert out.shape == (B, OC, OH, OW)
-    rc = _hip.lib().acktr_conv2d_fwd_f32(
-        _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
-        B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0, _hip.cur_stream(x.device))
+    with _Timed('conv%ds%d_fwd' % (KH, stride), 2.0 * B * OH * OW * OC * C * KH * KW):
+        rc = _hip.lib().acktr_conv2d_fwd_f32(
+            _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
+            B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0, _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_conv2d_fwd_f32')
     return out
 
@@ -60,10 +99,11 @@ def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=N
     L = _hip.lib()
     nbytes = L.acktr_conv2d_wgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride)
     ws = workspace(x.device, nbytes)
-    rc = L.acktr_conv2d_wgrad_f32(
-        _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(dy, 'dy'), _p(dw, 'dw'), _p(db, 'db'),
-        B, C, H, W, OC, KH, KW, stride, float(in_scale), _p(ws, 'workspace', torch.uint8), ws.numel(),
-        _hip.cur_stream(x.device))
+    with _Timed('conv%ds%d_wgrad' % (KH, stride), 2.0 * dy[0].numel() * B * C * KH * KW):
+        rc = L.acktr_conv2d_wgrad_f32(
+            _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(dy, 'dy'), _p(dw, 'dw'), _p(db, 'db'),
+            B, C, H, W, OC, KH, KW, stride, float(in_scale), _p(ws, 'workspace', torch.uint8), ws.numel(),
+            _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_conv2d_wgrad_f32')
 
 
@@ -75,8 +115,9 @@ def conv2d_dgrad(dy, w, x_act, stride, out=None):
     if out is None:
         out = torch.empty(B, C, H, W, dtype=f32, device=dy.device)
     assert out.shape == (B, C, H, W) and (x_act is None or x_act.shape == out.shape)
-    rc = _hip.lib().acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
-                                           B, C, H, W, OC, KH, KW, stride, _hip.cur_stream(dy.device))
+    with _Timed('conv%ds%d_dgrad' % (KH, stride), 2.0 * dy.numel() * C * KH * KW):
+        rc = _hip.lib().acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
+                                               B, C, H, W, OC, KH, KW, stride, _hip.cur_stream(dy.device))
     _hip.check(rc, 'acktr_conv2d_dgrad_f32')
     return out
 
@@ -90,8 +131,9 @@ def linear_fwd(x, w, bias, act=None, out=None):
     assert w.shape[1] == IN
     if out is None:
         out = torch.empty(B, OUT, dtype=f32, device=x.device)
-    rc = _hip.lib().acktr_linear_fwd_f32(_p(x, 'x'), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'), B, IN, OUT,
-                                         ACT[act], _hip.cur_stream(x.device))
+    with _Timed('linear%dx%d_fwd' % (IN, OUT), 2.0 * B * IN * OUT):
+        rc = _hip.lib().acktr_linear_fwd_f32(_p(x, 'x'), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'), B, IN, OUT,
+                                             ACT[act], _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_linear_fwd_f32')
     return out
 
@@ -103,9 +145,10 @@ def linear_dgrad(dy, w, gate_src=None, gate=None, out=None, accumulate=False):
     if out is None:
         assert not accumulate
         out = torch.empty(B, IN, dtype=f32, device=dy.device)
-    rc = _hip.lib().acktr_linear_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(gate_src, 'gate_src'), ACT[gate],
-                                           _p(out, 'dx'), B, IN, OUT, 1 if accumulate else 0,
-                                           _hip.cur_stream(dy.device))
+    with _Timed('linear%dx%d_dgrad' % (IN, OUT), 2.0 * B * IN * OUT):
+        rc = _hip.lib().acktr_linear_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(gate_src, 'gate_src'), ACT[gate],
+                                               _p(out, 'dx'), B, IN, OUT, 1 if accumulate else 0,
+                                               _hip.cur_stream(dy.device))
     _hip.check(rc, 'acktr_linear_dgrad_f32')
     return out
 
@@ -116,8 +159,9 @@ def linear_wgrad(dy, x, dw, db=None):
     assert x.shape[0] == B and dw.numel() == OUT * IN and (db is None or db.numel() == OUT)
     L = _hip.lib()
     ws = workspace(dy.device, L.acktr_linear_wgrad_workspace_bytes(B, IN, OUT))
-    rc = L.acktr_linear_wgrad_f32(_p(dy, 'dy'), _p(x, 'x'), _p(dw, 'dw'), _p(db, 'db'), B, IN, OUT,
-                                  _p(ws, 'workspace', torch.uint8), ws.numel(), _hip.cur_stream(dy.device))
+    with _Timed('linear%dx%d_wgrad' % (IN, OUT), 2.0 * B * IN * OUT):
+        rc = L.acktr_linear_wgrad_f32(_p(dy, 'dy'), _p(x, 'x'), _p(dw, 'dw'), _p(db, 'db'), B, IN, OUT,
+                                      _p(ws, 'workspace', torch.uint8), ws.numel(), _hip.cur_stream(dy.device))
     _hip.check(rc, 'acktr_linear_wgrad_f32')
 
 

@@ -125,6 +125,7 @@ typedef struct acktr_loss_args {
     float* dvalues;  long ld_dvalues;
     float* ddist;    long ld_ddist;
     float* dlogstd;
+    float* dlogstd_rows;   /* nullable [B,A]: per-sample d(loss)/d(logstd) (grad_output of the logstd AddBias, for KFAC) */
     float* logp_out;
     float* loss_acc;
     void* workspace; long workspace_bytes;
@@ -154,10 +155,53 @@ int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_
 /* clip_grad_norm_ + optim.RMSprop.step -- algo/a2c_acktr.py:74-78 (torch/optim/rmsprop.py:316-339). */
 int acktr_clip_rmsprop_f32(float* params, float* grads, float* square_avg, long n, float max_grad_norm, float lr,
                            float alpha, float eps, float* total_norm_out, void* workspace, void* stream);
-/* grads *= *grad_scale_dev (nullable; the KL-clip factor nu of kfac.py:234-239, kept on the device so no host
- * sync is needed) followed by optim.SGD(momentum).step -- kfac.py:139-142,241 (torch/optim/sgd.py:358-380). */
-int acktr_sgd_momentum_f32(float* params, float* grads, float* momentum_buf, long n, const float* grad_scale_dev,
-                           float lr, float momentum, int first_step, void* stream);
+/* grads = (update_src ? update_src : grads) * *grad_scale_dev (both nullable; p.grad <- v * nu of kfac.py:236-239,
+ * nu kept on the device so no host sync is needed) followed by optim.SGD(momentum).step -- kfac.py:139-142,241 (torch/optim/sgd.py:358-380). */
+int acktr_sgd_momentum_f32(float* params, float* grads, const float* update_src, float* momentum_buf, long n,
+                           const float* grad_scale_dev, float lr, float momentum, int first_step, void* stream);
+
+/* ---- KFAC (a2c_ppo_acktr/algo/kfac.py) ---------------------------------------------------- */
+
+/* compute_cov_a for a Conv2d input -- kfac.py:16-26,29-46.  out[Kc,Kc] = alpha * sum_{b,oy,ox} p p^T over the
+ * im2col patches p (index order (c,ky,kx)) of x[B,C,H,W]; the patch matrix is never materialised.
+ * The reference's scaling is alpha = in_scale^2 / (B_global * (OH*OW)^2).  Same geometries as conv2d_fwd.
+ * workspace: acktr_kfac_cov_workspace_bytes(Kc, B*OH*OW) for the split-K slabs. */
+long acktr_kfac_cov_workspace_bytes(int D, long reduction_len);
+int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_idx, int B, int C, int H, int W, int KH, int KW,
+                              int S, float alpha, float* out, void* workspace, long workspace_bytes, void* stream);
+/* compute_cov_g for a Conv2d grad_output -- kfac.py:49-64.  out[OC,OC] = alpha * sum_{b,sp} g g^T for
+ * dy[B,OC,SP]; reference scaling alpha = SP * B_global.  SP in {400, 81, 49}. */
+int acktr_kfac_cov_g_conv_f32(const float* dy, int B, int OC, int SP, float alpha, float* out, void* workspace,
+                              long workspace_bytes, void* stream);
+/* out[D,D] = alpha * a^T a for row-major a[B,D] with leading dimension lda: Linear inputs (alpha = 1/B_global, kfac.py:46) and
+ * Linear / AddBias grad_outputs (alpha = B_global, kfac.py:63-64). */
+int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, float alpha, float* out, void* workspace,
+                             long workspace_bytes, void* stream);
+/* out[row] = sum_sp g[row, sp] -- the AddBias branch of compute_cov_g, kfac.py:59-61. */
+int acktr_spatial_sum_f32(const float* g, int rows, int SP, float* out, void* stream);
+/* update_running_stat -- kfac.py:67-71: m = ((m * d/(1-d)) + x) * (1-d), three roundings; init != 0 first sets
+ * m = x (kfac.py:156-157,174-175). */
+int acktr_kfac_running_stat_f32(float* m, const float* x, long n, float stat_decay, int init, void* stream);
+
+/* torch.symeig(m, eigenvectors=True) + `d *= (d > thresh)` -- kfac.py:208-214.  Eigenvalues ascending;
+ * eigenvectors are returned as the ROWS of qt (qt = Q^T).
+ *  - batched Jacobi (hand-written, LDS resident): `descs_dev` is a device array of `count` structs
+ *    {const float* a; float* d; float* qt; int n;} (natural C layout, 32 bytes), every n <= max_n <= 128;
+ *  - rocSOLVER syevd for larger factors: in place on a (n x n), e_work[n] and info_dev[1] are scratch. */
+int acktr_jacobi_max_n(void);
+int acktr_sym_eig_jacobi_batched_f32(const void* descs_dev, int count, int max_n, float thresh, void* stream);
+int acktr_sym_eig_rocsolver_f32(float* a_inout_qt, int n, float* d, float* e_work, int* info_dev, float thresh,
+                                void* stream);
+
+/* v = Q_g [ (Q_g^T G Q_a) / (d_g d_a^T + damping) ] Q_a^T -- kfac.py:216-227, G = grad viewed [OUT, IN];
+ * tmp1, tmp2: OUT*IN floats each. */
+int acktr_kfac_precondition_f32(const float* grad, const float* qt_g, const float* d_g, const float* qt_a,
+                                const float* d_a, int OUT, int IN, float damping, float* tmp1, float* tmp2,
+                                float* v_out, void* stream);
+/* out[0] = vg_sum = lr^2 * <v, g>, out[1] = nu = min(1, sqrt(kl_clip / vg_sum)) -- kfac.py:229-234, on the
+ * device (the reference syncs to the host here).  workspace: acktr_optim_workspace_bytes(). */
+int acktr_kfac_kl_clip_f32(const float* v, const float* g, long n, float lr, float kl_clip, float* out_vgsum_nu,
+                           void* workspace, void* stream);
 
 #ifdef __cplusplus
 }

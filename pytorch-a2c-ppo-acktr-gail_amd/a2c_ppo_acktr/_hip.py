@@ -31,7 +31,7 @@ class LossArgs(ctypes.Structure):
                 ('clip', c_f), ('value_coef', c_f), ('entropy_coef', c_f), ('inv_batch', c_f),
                 ('use_clipped_value_loss', c_i),
                 ('dvalues', c_p), ('ld_dvalues', c_l), ('ddist', c_p), ('ld_ddist', c_l),
-                ('dlogstd', c_p), ('logp_out', c_p), ('loss_acc', c_p),
+                ('dlogstd', c_p), ('dlogstd_rows', c_p), ('logp_out', c_p), ('loss_acc', c_p),
                 ('workspace', c_p), ('workspace_bytes', c_l)]
 
 # name -> (restype, argtypes); mirrors include/acktr_hip.h one to one
@@ -59,7 +59,18 @@ _PROTOS = {
     'acktr_optim_workspace_bytes': (c_l, []),
     'acktr_clip_adam_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_clip_rmsprop_f32': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
-    'acktr_sgd_momentum_f32': (c_i, [c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_i, c_p]),
+    'acktr_sgd_momentum_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_i, c_p]),
+    'acktr_kfac_cov_workspace_bytes': (c_l, [c_i, c_l]),
+    'acktr_kfac_cov_a_conv_f32': (c_i, [c_p, c_p] + [c_i] * 7 + [c_f, c_p, c_p, c_l, c_p]),
+    'acktr_kfac_cov_g_conv_f32': (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_l, c_p]),
+    'acktr_kfac_cov_dense_f32': (c_i, [c_p, c_l, c_i, c_i, c_f, c_p, c_p, c_l, c_p]),
+    'acktr_spatial_sum_f32': (c_i, [c_p, c_i, c_i, c_p, c_p]),
+    'acktr_kfac_running_stat_f32': (c_i, [c_p, c_p, c_l, c_f, c_i, c_p]),
+    'acktr_jacobi_max_n': (c_i, []),
+    'acktr_sym_eig_jacobi_batched_f32': (c_i, [c_p, c_i, c_i, c_f, c_p]),
+    'acktr_sym_eig_rocsolver_f32': (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p]),
+    'acktr_kfac_precondition_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'acktr_kfac_kl_clip_f32': (c_i, [c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p]),
 }
 
 

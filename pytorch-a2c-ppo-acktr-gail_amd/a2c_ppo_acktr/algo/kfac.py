@@ -1,0 +1,349 @@
+"""KFACOptimizer -- host-side mirror of reference a2c_ppo_acktr/algo/kfac.py:74-242.
+
+Same constructor, `split_bias` model surgery (parameter names become `*.module.weight` /
+`*.add_bias._bias`), public attributes (`steps, Ts, Tf, lr, acc_stats, m_aa, m_gg, Q_a, Q_g, d_a, d_g,
+modules`) and `step()` contract.  The reference gathers its statistics through forward-pre / backward
+hooks on torch modules; here the HIP engine already holds every layer's input and pre-activation
+gradient, so `A2C_ACKTR.update` calls `accumulate_stats()` where the hooks would have fired.
+
+Device data layout: all A factors live in one flat fp32 bucket, all G factors in another (sample and
+running-average twins) -- one RCCL all-reduce each under data parallelism; eigenvectors are stored as
+ROWS (`qt = Q^T`), eigenvalues ascending.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from .. import _hip, engine, ops
+from ..utils import AddBias
+
+f32 = torch.float32
+
+
+class SplitBias(nn.Module):
+    """reference kfac.py:74-84: bias-less module followed by an AddBias holding the former bias."""
+
+    def __init__(self, module):
+        super(SplitBias, self).__init__()
+        self.module = module
+        self.add_bias = AddBias(module.bias.data)
+        self.module.bias = None
+
+
+class _JacobiDesc(ctypes.Structure):
+    _fields_ = [('a', ctypes.c_void_p), ('d', ctypes.c_void_p), ('qt', ctypes.c_void_p), ('n', ctypes.c_int)]
+
+
+class _Mod(object):
+    """Per known-module bookkeeping: which engine layer it belongs to and its factor slots."""
+    __slots__ = ('module', 'param', 'layer', 'role', 'kind', 'na', 'ng', 'oa', 'og', 'da_off', 'dg_off')
+
+
+class KFACOptimizer(optim.Optimizer):
+    def __init__(self,
+                 model,
+                 lr=0.25,
+                 momentum=0.9,
+                 stat_decay=0.99,
+                 kl_clip=0.001,
+                 damping=1e-2,
+                 weight_decay=0,
+                 fast_cnn=False,
+                 Ts=1,
+                 Tf=10):
+        defaults = dict()
+
+        def split_bias(module):
+            for mname, child in module.named_children():
+                if hasattr(child, 'bias') and child.bias is not None:
+                    module._modules[mname] = SplitBias(child)
+                else:
+                    split_bias(child)
+
+        split_bias(model)
+        model.rebind_flat()
+
+        super(KFACOptimizer, self).__init__(model.parameters(), defaults)
+
+        if fast_cnn:
+            raise NotImplementedError('fast_cnn=True (kfac.py:33-36,53-55) is never used by the reference driver; not built')
+
+        self.known_modules = {'Linear', 'Conv2d', 'AddBias'}
+
+        self.modules = []
+        self.grad_outputs = {}
+
+        self.model = model
+        self._prepare_model()
+
+        self.steps = 0
+
+        self.m_aa, self.m_gg = {}, {}
+        self.Q_a, self.Q_g = {}, {}
+        self.d_a, self.d_g = {}, {}
+
+        self.momentum = momentum
+        self.stat_decay = stat_decay
+
+        self.lr = lr
+        self.kl_clip = kl_clip
+        self.damping = damping
+        self.weight_decay = weight_decay
+
+        self.fast_cnn = fast_cnn
+
+        self.Ts = Ts
+        self.Tf = Tf
+        self.acc_stats = False
+
+        # inner SGD(lr*(1-momentum), momentum) of kfac.py:139-142, on the flat buffers
+        self.sgd_lr = self.lr * (1 - self.momentum)
+        self._mom_buf = None
+        self._ready_device = None
+
+    # ------------------------------------------------------------------ module discovery (kfac.py:179-188)
+    def _prepare_model(self):
+        pol = self.model
+        layers = engine.cnn_layer_params(pol) if engine.is_cnn(pol) else engine.mlp_layer_params(pol)
+        owner = {}
+        for lname, (w, b) in layers.items():
+            owner[id(w)] = (lname, 'w')
+            owner[id(b)] = (lname, 'b')
+        if not engine.is_cnn(pol):
+            owner[id(engine.logstd_param(pol))] = ('logstd', 'b')
+        self._mods = []
+        for module in pol.modules():
+            classname = module.__class__.__name__
+            if classname in self.known_modules:
+                assert not ((classname in ['Linear', 'Conv2d']) and module.bias is not None), \
+                    "You must have a bias as a separate layer"
+                self.modules.append(module)
+                ps = list(module.parameters())
+                assert len(ps) == 1, "Can handle only one parameter at the moment"
+                m = _Mod()
+                m.module, m.param = module, ps[0]
+                m.layer, m.role = owner[id(ps[0])]
+                m.kind = classname
+                p = ps[0]
+                m.ng = p.shape[0]
+                m.na = 1 if classname == 'AddBias' else p[0].numel()
+                self._mods.append(m)
+
+    def _setup(self, dev):
+        """Allocate factor buckets, eigen storage and scratch on `dev` (first use)."""
+        if self._ready_device == dev:
+            return
+        oa = og = 0
+        da = dg = 0
+        for m in self._mods:
+            m.oa, m.og = oa, og
+            m.da_off, m.dg_off = da, dg
+            al4 = lambda n: (n + 3) // 4 * 4                      # keep every slot 16-byte aligned (float4 loads)
+            oa += al4(m.na * m.na)
+            og += al4(m.ng * m.ng)
+            da += al4(m.na)
+            dg += al4(m.ng)
+        z = lambda n: torch.zeros(n, dtype=f32, device=dev)
+        self.aa_sample, self.gg_sample = z(oa), z(og)
+        self.aa_run, self.gg_run = z(oa), z(og)
+        self.qt_a, self.qt_g = z(oa), z(og)
+        self.d_a_flat, self.d_g_flat = z(da), z(dg)
+        for m in self._mods:
+            mod = m.module
+            self.m_aa[mod] = self.aa_run[m.oa:m.oa + m.na * m.na].view(m.na, m.na)
+            self.m_gg[mod] = self.gg_run[m.og:m.og + m.ng * m.ng].view(m.ng, m.ng)
+            self.Q_a[mod] = self.qt_a[m.oa:m.oa + m.na * m.na].view(m.na, m.na).t()
+            self.Q_g[mod] = self.qt_g[m.og:m.og + m.ng * m.ng].view(m.ng, m.ng).t()
+            self.d_a[mod] = self.d_a_flat[m.da_off:m.da_off + m.na]
+            self.d_g[mod] = self.d_g_flat[m.dg_off:m.dg_off + m.ng]
+        self.v_flat = torch.zeros_like(self.model.flat_params)
+        mx = max(m.na * m.ng for m in self._mods)
+        self.tmp1, self.tmp2 = z(mx), z(mx)
+        self.nu_buf = z(2)
+        nmax = max(max(m.na, m.ng) for m in self._mods)
+        self.e_work = z(nmax)
+        self.info = torch.zeros(1, dtype=torch.int32, device=dev)
+        # batched-Jacobi descriptors for every small factor (built once: pointers are stable)
+        L = _hip.lib()
+        jmax = L.acktr_jacobi_max_n()
+        descs, self._big = [], []
+        self._jac_max = 1
+        for m in self._mods:
+            for (run, qt, dfl, off, doff, n) in ((self.aa_run, self.qt_a, self.d_a_flat, m.oa, m.da_off, m.na),
+                                                 (self.gg_run, self.qt_g, self.d_g_flat, m.og, m.dg_off, m.ng)):
+                if n <= jmax:
+                    d = _JacobiDesc(run.data_ptr() + 4 * off, dfl.data_ptr() + 4 * doff, qt.data_ptr() + 4 * off, n)
+                    descs.append(d)
+                    self._jac_max = max(self._jac_max, n)
+                else:
+                    self._big.append((run, qt, dfl, off, doff, n))
+        arr = (_JacobiDesc * len(descs))(*descs)
+        raw = bytes(arr)
+        self._jac_descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self._jac_count = len(descs)
+        self._ready_device = dev
+
+    # ------------------------------------------------------------------ statistics (kfac.py:144-177)
+    def _cov_dense(self, a2d, ptr, ld, B, D, alpha, out):
+        L = _hip.lib()
+        ws = ops.workspace(out.device, L.acktr_kfac_cov_workspace_bytes(D, B), 'kfac')
+        rc = L.acktr_kfac_cov_dense_f32(ptr, ld, B, D, float(alpha), _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(),
+                                        _hip.cur_stream(out.device))
+        _hip.check(rc, 'acktr_kfac_cov_dense_f32')
+
+    def accumulate_stats(self, acts, actions, gather_idx, inv_batch, dp):
+        """What the reference's hooks do during the forward (compute_cov_a on every layer input) and during
+        the sampled-Fisher backward (compute_cov_g on every grad_output), a2c_acktr.py:53-68."""
+        pol = self.model
+        cnn = acts.cnn
+        dev = acts.head.device if cnn else acts.v.device
+        self._setup(dev)
+        L = _hip.lib()
+        B = acts.head.shape[0] if cnn else acts.v.shape[0]       # local rows
+        Bg = int(round(1.0 / inv_batch))                         # global batch (kfac.py:30,50 use the full batch)
+        stream = _hip.cur_stream(dev)
+        view_a = lambda m: self.aa_sample[m.oa:m.oa + m.na * m.na]
+        view_g = lambda m: self.gg_sample[m.og:m.og + m.ng * m.ng]
+
+        # ---- A factors: compute_cov_a on the layer inputs (kfac.py:29-46)
+        if cnn:
+            conv_in = {'conv1': (acts.obs, acts.idx, 1.0 / 255.0, 4), 'conv2': (acts.y1, None, 1.0, 2),
+                       'conv3': (acts.y2, None, 1.0, 1)}
+            lin_in = {'fc': acts.flat3, 'critic': acts.feat, 'actor': acts.feat}
+        else:
+            conv_in = {}
+            lin_in = {'a0': acts.obs, 'a2': acts.ha1, 'c0': acts.obs, 'c2': acts.hc1, 'critic': acts.hc2,
+                      'mean': acts.ha2}
+        for m in self._mods:
+            out = view_a(m)
+            if m.kind == 'AddBias':
+                out.fill_(float(B) / Bg)                          # ones^T (ones / B_global) over the local rows
+            elif m.kind == 'Conv2d':
+                x, idx, sc, stride = conv_in[m.layer]
+                OC, C, KH, KW = m.param.shape
+                H, W = x.shape[-2], x.shape[-1]
+                OH, OW = (H - KH) // stride + 1, (W - KW) // stride + 1
+                alpha = (sc * sc) / (float(Bg) * float(OH * OW) ** 2)
+                ws = ops.workspace(dev, L.acktr_kfac_cov_workspace_bytes(C * KH * KW, B * OH * OW), 'kfac')
+                rc = L.acktr_kfac_cov_a_conv_f32(_hip.dev_ptr(x), _hip.dev_ptr(idx, torch.int64), B, C, H, W, KH, KW,
+                                                 stride, alpha, _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(), stream)
+                _hip.check(rc, 'acktr_kfac_cov_a_conv_f32')
+            else:
+                a = lin_in[m.layer]
+                self._cov_dense(a, a.data_ptr(), a.shape[1], B, a.shape[1], 1.0 / Bg, out)
+
+        # ---- sampled Fisher loss and its data-gradient chain (a2c_acktr.py:56-68)
+        rows_total = Bg
+        noise = torch.randn(rows_total, 1)                        # CPU default generator, like the reference (F7)
+        noise = noise.to(dev, non_blocking=True).view(-1)
+        dls_rows = None
+        if not cnn:
+            dls_rows = torch.empty(B, pol.dist.num_outputs, dtype=f32, device=dev)
+        scratch_g = self.v_flat                                   # d logstd sum lands here; overwritten in step()
+        engine.policy_loss(pol, acts, engine.ALGO_FISHER, actions, None, inv_batch, adv=noise, gather_idx=gather_idx,
+                           gflat=scratch_g, dlogstd_rows=dls_rows)
+        engine.backward(pol, acts, scratch_g, keep=True, wgrad=False)
+
+        # ---- G factors: compute_cov_g on the grad_outputs (kfac.py:49-64)
+        if cnn:
+            conv_g = {'conv1': acts.dy1, 'conv2': acts.dy2, 'conv3': acts.dy3}
+            A = pol.dist.num_outputs
+            hp, hl = acts.dhead.data_ptr(), acts.dhead.shape[1]
+            lin_g = {'fc': (acts.dfeat.data_ptr(), acts.dfeat.shape[1], acts.dfeat.shape[1]),
+                     'critic': (hp, hl, 1), 'actor': (hp + 4, hl, A)}
+        else:
+            conv_g = {}
+            A = pol.dist.num_outputs
+            lin_g = {'a0': (acts.dha1.data_ptr(), acts.dha1.shape[1], acts.dha1.shape[1]),
+                     'a2': (acts.dha2.data_ptr(), acts.dha2.shape[1], acts.dha2.shape[1]),
+                     'c0': (acts.dhc1.data_ptr(), acts.dhc1.shape[1], acts.dhc1.shape[1]),
+                     'c2': (acts.dhc2.data_ptr(), acts.dhc2.shape[1], acts.dhc2.shape[1]),
+                     'critic': (acts.dv.data_ptr(), 1, 1), 'mean': (acts.dmean.data_ptr(), A, A),
+                     'logstd': (dls_rows.data_ptr(), A, A)}
+        for m in self._mods:
+            out = view_g(m)
+            if m.layer in conv_g:
+                dy = conv_g[m.layer]
+                OC, SP = dy.shape[1], dy.shape[2] * dy.shape[3]
+                if m.kind == 'Conv2d':
+                    ws = ops.workspace(dev, L.acktr_kfac_cov_workspace_bytes(OC, B * SP), 'kfac')
+                    rc = L.acktr_kfac_cov_g_conv_f32(_hip.dev_ptr(dy), B, OC, SP, float(SP) * Bg, _hip.dev_ptr(out),
+                                                     _hip.dev_ptr(ws), ws.numel(), stream)
+                    _hip.check(rc, 'acktr_kfac_cov_g_conv_f32')
+                else:                                              # AddBias after a conv: sum over space first
+                    ssum = torch.empty(B, OC, dtype=f32, device=dev)
+                    rc = L.acktr_spatial_sum_f32(_hip.dev_ptr(dy), B * OC, SP, _hip.dev_ptr(ssum), stream)
+                    _hip.check(rc, 'acktr_spatial_sum_f32')
+                    self._cov_dense(ssum, ssum.data_ptr(), OC, B, OC, float(Bg), out)
+            else:
+                ptr, ld, D = lin_g[m.layer]
+                self._cov_dense(None, ptr, ld, B, D, float(Bg), out)
+
+        # ---- data-parallel: SUM the sample factors (global scalings already applied), then running averages
+        dp.all_reduce_sum_(self.aa_sample)
+        dp.all_reduce_sum_(self.gg_sample)
+        init = 1 if self.steps == 0 else 0
+        for run, smp in ((self.aa_run, self.aa_sample), (self.gg_run, self.gg_sample)):
+            rc = L.acktr_kfac_running_stat_f32(_hip.dev_ptr(run), _hip.dev_ptr(smp), run.numel(), self.stat_decay, init,
+                                               stream)
+            _hip.check(rc, 'acktr_kfac_running_stat_f32')
+
+    # ------------------------------------------------------------------ eigendecompositions (kfac.py:205-214)
+    def _eigendecompose(self):
+        L = _hip.lib()
+        dev = self.aa_run.device
+        stream = _hip.cur_stream(dev)
+        if self._jac_count:
+            rc = L.acktr_sym_eig_jacobi_batched_f32(_hip.dev_ptr(self._jac_descs, torch.uint8), self._jac_count,
+                                                    self._jac_max, 1e-6, stream)
+            _hip.check(rc, 'acktr_sym_eig_jacobi_batched_f32')
+        for run, qt, dfl, off, doff, n in self._big:
+            q = qt[off:off + n * n]
+            q.copy_(run[off:off + n * n])
+            rc = L.acktr_sym_eig_rocsolver_f32(_hip.dev_ptr(q), n, ctypes.c_void_p(dfl.data_ptr() + 4 * doff),
+                                               _hip.dev_ptr(self.e_work), _hip.dev_ptr(self.info, torch.int32), 1e-6,
+                                               stream)
+            _hip.check(rc, 'acktr_sym_eig_rocsolver_f32')
+
+    # ------------------------------------------------------------------ step (kfac.py:190-242)
+    def step(self):
+        pol = self.model
+        flat, gflat = pol.flat_params, pol.flat_grads
+        dev = flat.device
+        self._setup(dev)
+        L = _hip.lib()
+        stream = _hip.cur_stream(dev)
+        with torch.no_grad():
+            if self.weight_decay > 0:
+                gflat.add_(flat, alpha=self.weight_decay)         # kfac.py:192-194 (never enabled by the reference driver)
+            la = self.damping + self.weight_decay
+            if self.steps % self.Tf == 0:
+                self._eigendecompose()
+            for m in self._mods:
+                g = pol.grad_view(m.param, gflat)
+                v = pol.grad_view(m.param, self.v_flat)
+                rc = L.acktr_kfac_precondition_f32(
+                    _hip.dev_ptr(g), ctypes.c_void_p(self.qt_g.data_ptr() + 4 * m.og),
+                    ctypes.c_void_p(self.d_g_flat.data_ptr() + 4 * m.dg_off),
+                    ctypes.c_void_p(self.qt_a.data_ptr() + 4 * m.oa),
+                    ctypes.c_void_p(self.d_a_flat.data_ptr() + 4 * m.da_off), m.ng, m.na, float(la),
+                    _hip.dev_ptr(self.tmp1), _hip.dev_ptr(self.tmp2), _hip.dev_ptr(v), stream)
+                _hip.check(rc, 'acktr_kfac_precondition_f32')
+            ws = ops.workspace(dev, L.acktr_optim_workspace_bytes(), 'optim')
+            rc = L.acktr_kfac_kl_clip_f32(_hip.dev_ptr(self.v_flat), _hip.dev_ptr(gflat), flat.numel(), float(self.lr),
+                                          float(self.kl_clip), _hip.dev_ptr(self.nu_buf), _hip.dev_ptr(ws), stream)
+            _hip.check(rc, 'acktr_kfac_kl_clip_f32')
+            first = self._mom_buf is None
+            if first:
+                self._mom_buf = torch.zeros_like(flat)
+            rc = L.acktr_sgd_momentum_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.v_flat),
+                                          _hip.dev_ptr(self._mom_buf), flat.numel(),
+                                          ctypes.c_void_p(self.nu_buf.data_ptr() + 4), float(self.sgd_lr),
+                                          float(self.momentum), 1 if first else 0, stream)
+            _hip.check(rc, 'acktr_sgd_momentum_f32')
+        self.steps += 1
+
+    def zero_grad(self, set_to_none=False):
+        self.model.flat_grads.zero_()

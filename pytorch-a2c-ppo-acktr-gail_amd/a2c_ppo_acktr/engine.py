@@ -140,42 +140,50 @@ def seed_ptrs(acts):
     return acts.dv.data_ptr(), 1, acts.dmean.data_ptr(), acts.dmean.shape[1]
 
 
-def backward(policy, acts, gflat, keep=False):
+def backward(policy, acts, gflat, keep=False, wgrad=True):
     """Parameter gradients of one batch into the flat gradient buffer `gflat` (overwrites, never
     accumulates).  With keep=True the pre-activation gradients of every layer stay on `acts`
-    (dy1, dy2, dy3, dfeat / dhc*, dha*) -- the `grad_output`s KFAC's backward hooks would see."""
+    (dy1, dy2, dy3, dfeat / dhc*, dha*) -- the `grad_output`s KFAC's backward hooks would see.
+    wgrad=False runs the data-gradient chain only (the sampled-Fisher pass of ACKTR needs no
+    parameter gradients, a2c_acktr.py:66-70)."""
     gv = lambda p: policy.grad_view(p, gflat)
     if acts.cnn:
         L = cnn_layer_params(policy)
         wh, _ = head_views(policy, policy.flat_params)
-        gwh, gbh = head_views(policy, gflat)
-        ops.linear_wgrad(acts.dhead, acts.feat, gwh, gbh)
-        dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
-        ops.linear_wgrad(dfeat, acts.flat3, gv(L['fc'][0]), gv(L['fc'][1]).view(-1))
-        dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
         w3, w2, w1 = L['conv3'][0], L['conv2'][0], L['conv1'][0]
-        ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
+        if wgrad:
+            gwh, gbh = head_views(policy, gflat)
+            ops.linear_wgrad(acts.dhead, acts.feat, gwh, gbh)
+        dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
+        if wgrad:
+            ops.linear_wgrad(dfeat, acts.flat3, gv(L['fc'][0]), gv(L['fc'][1]).view(-1))
+        dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
+        if wgrad:
+            ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
         dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1)
-        ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1))
+        if wgrad:
+            ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1))
         dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2)
-        ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1), in_scale=1.0 / 255.0,
-                         gather_idx=acts.idx)
+        if wgrad:
+            ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1),
+                             in_scale=1.0 / 255.0, gather_idx=acts.idx)
         if keep:
             acts.dfeat, acts.dy3, acts.dy2, acts.dy1 = dfeat, dy3, dy2, dy1
         return
     L = mlp_layer_params(policy)
     # critic tower
-    ops.linear_wgrad(acts.dv, acts.hc2, gv(L['critic'][0]), gv(L['critic'][1]).view(-1))
     dhc2 = ops.linear_dgrad(acts.dv, L['critic'][0], gate_src=acts.hc2, gate='tanh')
-    ops.linear_wgrad(dhc2, acts.hc1, gv(L['c2'][0]), gv(L['c2'][1]).view(-1))
     dhc1 = ops.linear_dgrad(dhc2, L['c2'][0], gate_src=acts.hc1, gate='tanh')
-    ops.linear_wgrad(dhc1, acts.obs, gv(L['c0'][0]), gv(L['c0'][1]).view(-1))
     # actor tower
-    ops.linear_wgrad(acts.dmean, acts.ha2, gv(L['mean'][0]), gv(L['mean'][1]).view(-1))
     dha2 = ops.linear_dgrad(acts.dmean, L['mean'][0], gate_src=acts.ha2, gate='tanh')
-    ops.linear_wgrad(dha2, acts.ha1, gv(L['a2'][0]), gv(L['a2'][1]).view(-1))
     dha1 = ops.linear_dgrad(dha2, L['a2'][0], gate_src=acts.ha1, gate='tanh')
-    ops.linear_wgrad(dha1, acts.obs, gv(L['a0'][0]), gv(L['a0'][1]).view(-1))
+    if wgrad:
+        ops.linear_wgrad(acts.dv, acts.hc2, gv(L['critic'][0]), gv(L['critic'][1]).view(-1))
+        ops.linear_wgrad(dhc2, acts.hc1, gv(L['c2'][0]), gv(L['c2'][1]).view(-1))
+        ops.linear_wgrad(dhc1, acts.obs, gv(L['c0'][0]), gv(L['c0'][1]).view(-1))
+        ops.linear_wgrad(acts.dmean, acts.ha2, gv(L['mean'][0]), gv(L['mean'][1]).view(-1))
+        ops.linear_wgrad(dha2, acts.ha1, gv(L['a2'][0]), gv(L['a2'][1]).view(-1))
+        ops.linear_wgrad(dha1, acts.obs, gv(L['a0'][0]), gv(L['a0'][1]).view(-1))
     if keep:
         acts.dhc2, acts.dhc1, acts.dha2, acts.dha1 = dhc2, dhc1, dha2, dha1
 
@@ -188,7 +196,7 @@ ALGO_PPO, ALGO_A2C, ALGO_FISHER = 0, 1, 2
 
 def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, old_values=None, returns=None,
                 adv=None, gather_idx=None, clip=0.0, value_coef=0.0, entropy_coef=0.0, use_clipped_value_loss=True,
-                gflat=None, logp_out=None):
+                gflat=None, logp_out=None, dlogstd_rows=None):
     """Launch the fused loss kernel; fills the seed buffers on `acts` (and d logstd into `gflat`)."""
     dev = acts.head.device if acts.cnn else acts.v.device
     L = _hip.lib()
@@ -215,6 +223,7 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
     dvp, dvld, ddp, ddld = seed_ptrs(acts)
     args.dvalues, args.ld_dvalues, args.ddist, args.ld_ddist = dvp, dvld, ddp, ddld
     args.logp_out = p(logp_out)
+    args.dlogstd_rows = p(dlogstd_rows)
     args.loss_acc = p(loss_acc)
     ws = ops.workspace(dev, L.acktr_policy_loss_workspace_bytes(B, A), 'loss')
     args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()

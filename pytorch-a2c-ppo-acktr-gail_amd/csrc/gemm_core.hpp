@@ -274,14 +274,17 @@ struct RowMajorEpi {
     float* c; int M; int N; long ldc; long slab_stride;
     const float* bias_n; const float* bias_m; float scale; int act;
     const float* gate_src; long ldg; int gate; int accumulate;
-    struct Col { int n; int ok; float bn; };
+    const float* div_m; const float* div_n; float div_add;     // v /= (div_m[m]*div_n[n] + div_add)  (KFAC damping)
+    struct Col { int n; int ok; float bn; float dn; };
     __device__ __forceinline__ Col col(int n) const {
-        Col cc; cc.n = n; cc.ok = n < N; cc.bn = (cc.ok && bias_n) ? bias_n[n] : 0.f; return cc;
+        Col cc; cc.n = n; cc.ok = n < N; cc.bn = (cc.ok && bias_n) ? bias_n[n] : 0.f;
+        cc.dn = (cc.ok && div_n) ? div_n[n] : 0.f; return cc;
     }
     __device__ __forceinline__ void st(const Col& cc, int m, float acc, int ks) const {
         if (!cc.ok || m >= M) return;
         float v = acc * scale + cc.bn;
         if (bias_m) v += bias_m[m];
+        if (div_m) v = v / (div_m[m] * cc.dn + div_add);
         if (act == 1) v = v > 0.f ? v : 0.f;
         else if (act == 2) v = tanhf(v);
         if (gate == 1) v = gate_src[(long)m * ldg + cc.n] > 0.f ? v : 0.f;
@@ -293,7 +296,8 @@ struct RowMajorEpi {
 };
 static inline RowMajorEpi row_major_epi(float* c, int M, int N, long ldc) {
     RowMajorEpi e; e.c = c; e.M = M; e.N = N; e.ldc = ldc; e.slab_stride = 0; e.bias_n = nullptr; e.bias_m = nullptr;
-    e.scale = 1.f; e.act = 0; e.gate_src = nullptr; e.ldg = 0; e.gate = 0; e.accumulate = 0; return e;
+    e.scale = 1.f; e.act = 0; e.gate_src = nullptr; e.ldg = 0; e.gate = 0; e.accumulate = 0;
+    e.div_m = nullptr; e.div_n = nullptr; e.div_add = 0.f; return e;
 }
 
 // Fixed-order slab reduction: dst[i] (=|+=) scale * sum_s slabs[s*stride + i]

@@ -1,0 +1,400 @@
+// KFAC (reference a2c_ppo_acktr/algo/kfac.py) on MI355X:
+//   * Kronecker-factor statistics (compute_cov_a / compute_cov_g, kfac.py:29-64) as implicit-im2col SYRKs on
+//     the fp32 MFMA tile GEMM -- the patch matrix of kfac.py:16-26 is never materialised;
+//   * running averages (kfac.py:67-71) as one elementwise pass over the flat factor bucket (after the
+//     data-parallel all-reduce of the sample factors);
+//   * symmetric eigendecompositions (kfac.py:205-214): hand-written batched parallel-order Jacobi in LDS for
+//     small factors (n <= 128, one workgroup per matrix), rocSOLVER syevd for the large ones;
+//   * Kronecker-eigenbasis preconditioning (kfac.py:216-227) as four MFMA GEMMs with the damped division
+//     fused into the second one's epilogue;
+//   * KL clip (kfac.py:229-239) computed on the device (no host sync) feeding the SGD-momentum kernel.
+#include <rocsolver/rocsolver.h>
+
+#include "conv_ops.hpp"
+#include "../../include/acktr_hip.h"
+
+namespace acktr {
+int pick_slices(long tiles, long K, long max_by_ws);
+int gemm_rowmajor(const float* a, long a_srow, long a_sk, const float* b, long b_srow, long b_sk, const RowMajorEpi& epi,
+                  int M, int N, int K, int nslices, hipStream_t s);
+
+// ------------------------------------------------------------------------------------------ factor SYRKs
+template <int KH, int KW, int S, int H, int W>
+static int cov_a_conv_t(const float* x, const int64_t* idx, int B, int C, float alpha, float* out, float* ws,
+                        long ws_floats, hipStream_t s) {
+    using Patch = Im2col<KH, KW, S, H, W, false>;
+    const int Kc = C * KH * KW, R = B * Patch::SP;
+    Patch pop{x, idx, C, (long)C * H * W, R, Kc};
+    const long tiles = (long)cdiv(Kc, 128) * cdiv(Kc, 128);
+    long max_by_ws = ws_floats / ((long)Kc * Kc);
+    int ns = pick_slices(tiles, R, max_by_ws < 1 ? 1 : max_by_ws);
+    if (ns > 1 && max_by_ws < ns) ns = 1;
+    if (ns == 1) {
+        RowMajorEpi e = row_major_epi(out, Kc, Kc, Kc);
+        e.scale = alpha;
+        return launch_gemm<128, 128, 2, 2>(pop, pop, e, Kc, Kc, R, 1, s);
+    }
+    RowMajorEpi e = row_major_epi(ws, Kc, Kc, Kc);
+    e.slab_stride = (long)Kc * Kc;
+    int rc = launch_gemm<128, 128, 2, 2>(pop, pop, e, Kc, Kc, R, ns, s);
+    if (rc) return rc;
+    return launch_slab_reduce(out, ws, ns, (long)Kc * Kc, (long)Kc * Kc, alpha, 0, s);
+}
+
+template <int SP>
+static int cov_g_conv_t(const float* dy, int B, int OC, float alpha, float* out, float* ws, long ws_floats,
+                        hipStream_t s) {
+    const int R = B * SP;
+    ConvOutKC<SP> gop{dy, OC, R};
+    long max_by_ws = ws_floats / ((long)OC * OC);
+    int ns = pick_slices(1, R, max_by_ws < 1 ? 1 : max_by_ws);
+    if (ns > 512) ns = 512;
+    if (ns > 1 && max_by_ws < ns) ns = 1;
+    RowMajorEpi e = row_major_epi(ns == 1 ? out : ws, OC, OC, OC);
+    if (ns == 1) e.scale = alpha; else e.slab_stride = (long)OC * OC;
+    int rc;
+    if (OC <= 32) rc = launch_gemm<32, 128, 1, 4>(gop, gop, e, OC, OC, R, ns, s);
+    else rc = launch_gemm<64, 128, 2, 2>(gop, gop, e, OC, OC, R, ns, s);
+    if (rc) return rc;
+    if (ns > 1) return launch_slab_reduce(out, ws, ns, (long)OC * OC, (long)OC * OC, alpha, 0, s);
+    return 0;
+}
+
+// s[b, oc] = sum_sp g[b, oc, sp]     (kfac.py:59-61)
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const float* g, int rows, int SP, float* out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);     // one wave per (b, oc) row
+    if (r >= rows) return;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int i = lane; i < SP; i += 64) s += g[(long)r * SP + i];
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s;
+}
+
+// m = ((m * d/(1-d)) + x) * (1-d)   (three roundings, kfac.py:67-71); first step: m := x before the update
+__global__ __launch_bounds__(256) void running_stat_kernel(float* m, const float* x, long n, float c1, float c2,
+                                                           int init) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float xi = x[i];
+        float mi = init ? xi : m[i];
+        mi = mi * c1;
+        mi = mi + xi;
+        mi = mi * c2;
+        m[i] = mi;
+    }
+}
+
+// ------------------------------------------------------------------------------------------ batched Jacobi
+// One workgroup per symmetric matrix (n <= 128), A and V resident in LDS (pitch n+1: conflict-free column
+// walks).  Parallel-order cyclic Jacobi: each of the m-1 rounds of a sweep applies m/2 disjoint rotations
+// (round-robin "circle" pairing), column update, then row update, V accumulates the rotations.
+// Output: eigenvalues ascending (thresholded: d *= (d > thresh), kfac.py:213-214), eigenvectors as ROWS of qt.
+struct JacobiDesc {
+    const float* a;   // n x n input (row major, symmetric)
+    float* d;         // n eigenvalues
+    float* qt;        // n x n, row j = eigenvector j
+    int n;
+};
+
+__global__ __launch_bounds__(256) void jacobi_batched_kernel(const JacobiDesc* descs, float thresh, int max_sweeps) {
+    extern __shared__ __attribute__((aligned(16))) float jl[];
+    __shared__ float cs[64][2];
+    __shared__ int pp[64], qq[64];
+    __shared__ int any_rot;
+    __shared__ float red[16];
+    const JacobiDesc de = descs[blockIdx.x];
+    const int n = de.n, P = n + 1, tid = threadIdx.x;
+    float* A = jl;
+    float* V = jl + (long)n * P;
+    float fro = 0.f;
+    for (int i = tid; i < n * n; i += 256) {
+        const int r = i / n, c = i % n;
+        const float v = de.a[i];
+        A[r * P + c] = v;
+        V[r * P + c] = (r == c) ? 1.f : 0.f;
+        fro += v * v;
+    }
+    fro = block_sum(fro, red);
+    if (tid == 0) red[0] = fro;
+    __syncthreads();
+    const float tiny = 1e-8f * sqrtf(red[0]) + 1e-37f;
+    __syncthreads();
+    const int m = (n + 1) & ~1;          // even number of players (one dummy if n is odd)
+    const int half = m / 2;
+    for (int sweep = 0; sweep < max_sweeps; ++sweep) {
+        if (tid == 0) any_rot = 0;
+        __syncthreads();
+        for (int round = 0; round < m - 1; ++round) {
+            if (tid < half) {
+                int p, q;
+                if (tid == 0) { p = m - 1; q = round; }
+                else { p = (round + tid) % (m - 1); q = (round - tid + (m - 1)) % (m - 1); }
+                if (p > q) { const int t = p; p = q; q = t; }
+                float c = 1.f, s = 0.f;
+                if (q < n) {
+                    const float apq = A[p * P + q];
+                    if (fabsf(apq) > tiny) {
+                        const float tau = (A[q * P + q] - A[p * P + p]) / (2.f * apq);
+                        const float t = (tau >= 0.f ? 1.f : -1.f) / (fabsf(tau) + sqrtf(1.f + tau * tau));
+                        c = 1.f / sqrtf(1.f + t * t);
+                        s = t * c;
+                        any_rot = 1;
+                    }
+                } else {
+                    q = p;                                   // dummy partner: identity
+                }
+                pp[tid] = p; qq[tid] = q; cs[tid][0] = c; cs[tid][1] = s;
+            }
+            __syncthreads();
+            // columns: A <- A J, V <- V J
+            for (int w = tid; w < half * n; w += 256) {
+                const int k = w / n, i = w % n;
+                const int p = pp[k], q = qq[k];
+                if (p != q) {
+                    const float c = cs[k][0], s = cs[k][1];
+                    const float aip = A[i * P + p], aiq = A[i * P + q];
+                    A[i * P + p] = c * aip - s * aiq;
+                    A[i * P + q] = s * aip + c * aiq;
+                    const float vip = V[i * P + p], viq = V[i * P + q];
+                    V[i * P + p] = c * vip - s * viq;
+                    V[i * P + q] = s * vip + c * viq;
+                }
+            }
+            __syncthreads();
+            // rows: A <- J^T A
+            for (int w = tid; w < half * n; w += 256) {
+                const int k = w / n, j = w % n;
+                const int p = pp[k], q = qq[k];
+                if (p != q) {
+                    const float c = cs[k][0], s = cs[k][1];
+                    const float apj = A[p * P + j], aqj = A[q * P + j];
+                    A[p * P + j] = c * apj - s * aqj;
+                    A[q * P + j] = s * apj + c * aqj;
+                }
+            }
+            __syncthreads();
+        }
+        if (!any_rot) break;
+        __syncthreads();
+    }
+    // ascending order by rank (stable), threshold, write eigenvectors as rows
+    for (int i = tid; i < n; i += 256) {
+        const float di = A[i * P + i];
+        int rank = 0;
+        for (int j = 0; j < n; ++j) {
+            const float dj = A[j * P + j];
+            rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
+        }
+        de.d[rank] = di > thresh ? di : 0.f;
+        V[n * P + i] = (float)rank;       // spare row of V (pitch gives one extra column per row, use last row slot)
+    }
+    __syncthreads();
+    for (int w = tid; w < n * n; w += 256) {
+        const int col = w / n, i = w % n;         // eigenvector = column `col` of V
+        const int rank = (int)V[n * P + col];
+        de.qt[(long)rank * n + i] = V[i * P + col];
+    }
+}
+
+__global__ __launch_bounds__(256) void eig_threshold_kernel(float* d, int n, float thresh) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) { const float v = d[i]; d[i] = v > thresh ? v : 0.f; }
+}
+
+// ------------------------------------------------------------------------------------------ KL clip
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* a, const float* b, long n, double* partial) {
+    __shared__ double sm[16];
+    double s = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += (double)a[i] * (double)b[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// out[0] = vg_sum = lr^2 * dot ; out[1] = nu = min(1, sqrt(kl_clip / vg_sum))   (kfac.py:229-234)
+__global__ __launch_bounds__(64) void kl_clip_kernel(const double* partial, int nparts, float lr, float kl_clip,
+                                                     float* out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 64) s += partial[i];
+    s = wave_sum(s);
+    if (threadIdx.x == 0) {
+        const float vg = (float)s * lr * lr;
+        float nu = sqrtf(kl_clip / vg);
+        if (!(nu < 1.f)) nu = 1.f;       // also catches NaN (vg <= 0)
+        out[0] = vg;
+        out[1] = nu;
+    }
+}
+
+static rocblas_handle g_handle = nullptr;
+static int ensure_handle(hipStream_t s) {
+    if (!g_handle) {
+        if (rocblas_create_handle(&g_handle) != rocblas_status_success) {
+            set_error("rocblas_create_handle failed");
+            g_handle = nullptr;
+            return -1;
+        }
+    }
+    if (rocblas_set_stream(g_handle, s) != rocblas_status_success) {
+        set_error("rocblas_set_stream failed");
+        return -1;
+    }
+    return 0;
+}
+}  // namespace acktr
+
+using namespace acktr;
+
+extern "C" long acktr_kfac_cov_workspace_bytes(int D, long R) {
+    const long tiles = (long)cdiv(D, 128) * cdiv(D, 128);
+    int ns = pick_slices(tiles, R, 1024);
+    if (ns > 512) ns = 512;
+    return (long)ns * D * D * (long)sizeof(float);
+}
+
+extern "C" int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_idx, int B, int C, int H, int W,
+                                         int KH, int KW, int S, float alpha, float* out, void* workspace,
+                                         long workspace_bytes, void* stream) {
+    ACKTR_ARG(x && out, "kfac_cov_a_conv: null pointer");
+    ACKTR_ARG(B > 0 && C > 0, "kfac_cov_a_conv: bad sizes");
+    ACKTR_ARG(((uintptr_t)x & 15) == 0, "kfac_cov_a_conv: x must be 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const long wf = workspace ? workspace_bytes / (long)sizeof(float) : 0;
+    if (H == 84 && W == 84 && KH == 8 && KW == 8 && S == 4) return cov_a_conv_t<8, 8, 4, 84, 84>(x, gather_idx, B, C, alpha, out, ws, wf, s);
+    if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2) return cov_a_conv_t<4, 4, 2, 20, 20>(x, gather_idx, B, C, alpha, out, ws, wf, s);
+    if (H == 9 && W == 9 && KH == 3 && KW == 3 && S == 1) return cov_a_conv_t<3, 3, 1, 9, 9>(x, gather_idx, B, C, alpha, out, ws, wf, s);
+    set_error("kfac_cov_a_conv: unsupported geometry %dx%d k%dx%d s%d", H, W, KH, KW, S);
+    return -1;
+}
+
+extern "C" int acktr_kfac_cov_g_conv_f32(const float* dy, int B, int OC, int SP, float alpha, float* out,
+                                         void* workspace, long workspace_bytes, void* stream) {
+    ACKTR_ARG(dy && out, "kfac_cov_g_conv: null pointer");
+    ACKTR_ARG(B > 0 && OC > 0, "kfac_cov_g_conv: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const long wf = workspace ? workspace_bytes / (long)sizeof(float) : 0;
+    if (SP == 400) return cov_g_conv_t<400>(dy, B, OC, alpha, out, ws, wf, s);
+    if (SP == 81) return cov_g_conv_t<81>(dy, B, OC, alpha, out, ws, wf, s);
+    if (SP == 49) return cov_g_conv_t<49>(dy, B, OC, alpha, out, ws, wf, s);
+    set_error("kfac_cov_g_conv: unsupported spatial size %d (supported 400, 81, 49)", SP);
+    return -1;
+}
+
+extern "C" int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, float alpha, float* out,
+                                        void* workspace, long workspace_bytes, void* stream) {
+    ACKTR_ARG(a && out, "kfac_cov_dense: null pointer");
+    ACKTR_ARG(B > 0 && D > 0 && lda >= D, "kfac_cov_dense: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const long wf = workspace ? workspace_bytes / (long)sizeof(float) : 0;
+    const long tiles = (long)cdiv(D, 128) * cdiv(D, 128);
+    long max_by_ws = wf / ((long)D * D);
+    int ns = pick_slices(tiles, B, max_by_ws < 1 ? 1 : max_by_ws);
+    if (ns > 1 && max_by_ws < ns) ns = 1;
+    // out[i, j] = alpha * sum_b a[b, i] a[b, j]  : both operands row contiguous (k = b)
+    if (ns == 1) {
+        RowMajorEpi e = row_major_epi(out, D, D, D);
+        e.scale = alpha;
+        return gemm_rowmajor(a, 1, lda, a, 1, lda, e, D, D, B, 1, s);
+    }
+    RowMajorEpi e = row_major_epi(ws, D, D, D);
+    e.slab_stride = (long)D * D;
+    int rc = gemm_rowmajor(a, 1, lda, a, 1, lda, e, D, D, B, ns, s);
+    if (rc) return rc;
+    return launch_slab_reduce(out, ws, ns, (long)D * D, (long)D * D, alpha, 0, s);
+}
+
+extern "C" int acktr_spatial_sum_f32(const float* g, int rows, int SP, float* out, void* stream) {
+    ACKTR_ARG(g && out && rows > 0 && SP > 0, "spatial_sum: bad arguments");
+    hipLaunchKernelGGL(spatial_sum_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, g, rows, SP, out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_kfac_running_stat_f32(float* m, const float* x, long n, float stat_decay, int init, void* stream) {
+    ACKTR_ARG(m && x && n > 0, "kfac_running_stat: bad arguments");
+    // python: momentum/(1-momentum) and (1-momentum) are doubles rounded to fp32 when applied to the fp32 tensor
+    const float c1 = (float)((double)stat_decay / (1.0 - (double)stat_decay));
+    const float c2 = (float)(1.0 - (double)stat_decay);
+    int nb = cdiv(n, 1024);
+    if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(running_stat_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, m, x, n, c1, c2, init);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_jacobi_max_n(void) { return 128; }
+
+extern "C" int acktr_sym_eig_jacobi_batched_f32(const void* descs_dev, int count, int max_n, float thresh,
+                                                void* stream) {
+    ACKTR_ARG(descs_dev && count > 0, "sym_eig_jacobi: bad arguments");
+    ACKTR_ARG(max_n >= 1 && max_n <= 128, "sym_eig_jacobi: n=%d exceeds the LDS-resident limit of 128", max_n);
+    const int smem = 2 * (max_n + 1) * (max_n + 1) * (int)sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(jacobi_batched_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 129 * 129 * 4);
+        if (e != hipSuccess) { set_error("jacobi: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(jacobi_batched_kernel, dim3(count), dim3(256), smem, (hipStream_t)stream,
+                       (const JacobiDesc*)descs_dev, thresh, 30);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_sym_eig_rocsolver_f32(float* a_inout_qt, int n, float* d, float* e_work, int* info_dev,
+                                           float thresh, void* stream) {
+    ACKTR_ARG(a_inout_qt && d && e_work && info_dev && n > 0, "sym_eig_rocsolver: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int rc = ensure_handle(s);
+    if (rc) return rc;
+    // column-major eigenvectors as columns == row-major rows: a_inout_qt[j*n + i] = component i of eigenvector j
+    rocblas_status st = rocsolver_ssyevd(g_handle, rocblas_evect_original, rocblas_fill_upper, n, a_inout_qt, n, d,
+                                         e_work, info_dev);
+    if (st != rocblas_status_success) {
+        set_error("rocsolver_ssyevd(n=%d) failed with status %d", n, (int)st);
+        return -1;
+    }
+    hipLaunchKernelGGL(eig_threshold_kernel, dim3(cdiv(n, 256)), dim3(256), 0, s, d, n, thresh);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_kfac_precondition_f32(const float* grad, const float* qt_g, const float* d_g, const float* qt_a,
+                                           const float* d_a, int OUT, int IN, float damping, float* tmp1, float* tmp2,
+                                           float* v_out, void* stream) {
+    ACKTR_ARG(grad && qt_g && d_g && qt_a && d_a && tmp1 && tmp2 && v_out, "kfac_precondition: null pointer");
+    ACKTR_ARG(OUT > 0 && IN > 0, "kfac_precondition: bad sizes");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    // T1 = Qg^T G      (Qg^T = qt_g)           [OUT x IN] : A(m,k) = qt_g[m,k], B(n,k) = grad[k,n]
+    RowMajorEpi e1 = row_major_epi(tmp1, OUT, IN, IN);
+    rc = gemm_rowmajor(qt_g, OUT, 1, grad, 1, IN, e1, OUT, IN, OUT, 1, s);
+    if (rc) return rc;
+    // T2 = (T1 Qa) / (d_g d_a^T + lambda)      : B(n,k) = Qa[k,n] = qt_a[n,k]
+    RowMajorEpi e2 = row_major_epi(tmp2, OUT, IN, IN);
+    e2.div_m = d_g; e2.div_n = d_a; e2.div_add = damping;
+    rc = gemm_rowmajor(tmp1, IN, 1, qt_a, IN, 1, e2, OUT, IN, IN, 1, s);
+    if (rc) return rc;
+    // T3 = Qg T2       : A(m,k) = Qg[m,k] = qt_g[k,m], B(n,k) = T2[k,n]
+    RowMajorEpi e3 = row_major_epi(tmp1, OUT, IN, IN);
+    rc = gemm_rowmajor(qt_g, 1, OUT, tmp2, 1, IN, e3, OUT, IN, OUT, 1, s);
+    if (rc) return rc;
+    // V = T3 Qa^T      : B(n,k) = Qa^T[k,n] = Qa[n,k] = qt_a[k,n]
+    RowMajorEpi e4 = row_major_epi(v_out, OUT, IN, IN);
+    return gemm_rowmajor(tmp1, IN, 1, qt_a, 1, IN, e4, OUT, IN, IN, 1, s);
+}
+
+extern "C" int acktr_kfac_kl_clip_f32(const float* v, const float* g, long n, float lr, float kl_clip,
+                                      float* out_vgsum_nu, void* workspace, void* stream) {
+    ACKTR_ARG(v && g && out_vgsum_nu && workspace && n > 0, "kfac_kl_clip: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    int nb = cdiv(n, 1024);
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, s, v, g, n, (double*)workspace);
+    ACKTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(kl_clip_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nb, lr, kl_clip, out_vgsum_nu);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}

@@ -158,6 +158,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_ar
                 const float var = sd * sd, dj = act_f[j] - din[j];
                 dd[j] = dlogp * dj / var;
                 dls[j] = dlogp * (dj * dj / var - 1.f) + dent;
+                if (a.dlogstd_rows) a.dlogstd_rows[(long)b * A + j] = dls[j];
             }
         }
     }

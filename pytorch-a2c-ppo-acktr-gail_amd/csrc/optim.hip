@@ -77,13 +77,13 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
 }
 
 // grad *= scale (device scalar, optional) ; SGD momentum: buf = first ? g : mom*buf + g ; p -= lr*buf
-__global__ __launch_bounds__(OPT_THREADS) void sgd_momentum_kernel(float* p, float* g, float* buf, long n,
-                                                                   const float* grad_scale, float lr, float momentum,
-                                                                   int first) {
+__global__ __launch_bounds__(OPT_THREADS) void sgd_momentum_kernel(float* p, float* g, const float* src, float* buf,
+                                                                   long n, const float* grad_scale, float lr,
+                                                                   float momentum, int first) {
     const float sc = grad_scale ? *grad_scale : 1.0f;
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
-        float gi = g[i];
-        if (grad_scale) { gi = gi * sc; g[i] = gi; }
+        float gi = src ? src[i] : g[i];
+        if (grad_scale || src) { gi = gi * sc; g[i] = gi; }
         float b;
         if (first) b = gi;
         else b = buf[i] * momentum + gi;
@@ -142,13 +142,13 @@ extern "C" int acktr_clip_rmsprop_f32(float* params, float* grads, float* square
     return 0;
 }
 
-extern "C" int acktr_sgd_momentum_f32(float* params, float* grads, float* momentum_buf, long n,
-                                      const float* grad_scale_dev, float lr, float momentum, int first_step,
+extern "C" int acktr_sgd_momentum_f32(float* params, float* grads, const float* update_src, float* momentum_buf,
+                                      long n, const float* grad_scale_dev, float lr, float momentum, int first_step,
                                       void* stream) {
     ACKTR_ARG(params && grads && momentum_buf, "sgd_momentum: null pointer");
     ACKTR_ARG(n > 0, "sgd_momentum: n must be positive");
     hipLaunchKernelGGL(sgd_momentum_kernel, dim3(grid_for(n)), dim3(OPT_THREADS), 0, (hipStream_t)stream, params, grads,
-                       momentum_buf, n, grad_scale_dev, lr, momentum, first_step);
+                       update_src, momentum_buf, n, grad_scale_dev, lr, momentum, first_step);
     ACKTR_LAUNCH_CHECK();
     return 0;
 }

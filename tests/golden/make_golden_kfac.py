@@ -1,0 +1,47 @@
+"""Golden vectors for the ACKTR / KFAC path from the REFERENCE (build container only); see make_golden.py."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    import make_golden as mg          # installs the reference import harness
+    import synth
+    import ref_harness
+    from a2c_ppo_acktr import algo    # reference
+    out = {}
+    cases = [('cnn', 'cnn', None, 6, 20, 32), ('mlp', 'mlp', 17, 6, 5, 16)]
+    for ci, (tag, kind, od, A, T, N) in enumerate(cases):
+        pol, P = mg.make_policy(kind, 90 + ci, od, A)
+        obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+        space = ref_harness.Discrete(A) if kind == 'cnn' else ref_harness.Box(A)
+        ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=820 + ci)
+        rs = mg.fill_storage(ro, obs_shape, space)
+        rs.compute_returns(mg.t(ro['next_value']), False, 0.99, 0.95, False)
+        agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
+        agent.optimizer.Tf = 2            # public attribute (kfac.py:137): eigendecompose at steps 0 and 2
+        names = [n for n, _ in pol.named_parameters()]
+        out[tag + '/param_names'] = np.array(names)
+        for it in range(3):
+            torch.manual_seed(555 + it)
+            res = agent.update(rs)
+            out[tag + '/update%d/losses' % it] = np.array(res, dtype=np.float64)
+            for n, p in pol.named_parameters():
+                mg.summarize(tag + '/update%d/param/%s' % (it, n), p.detach().numpy(), out)
+                mg.summarize(tag + '/update%d/kfgrad/%s' % (it, n), p.grad.detach().numpy(), out)
+            for i, m in enumerate(agent.optimizer.modules):
+                for fam, d in (('m_aa', agent.optimizer.m_aa), ('m_gg', agent.optimizer.m_gg)):
+                    mat = d[m].detach().numpy()
+                    mg.summarize(tag + '/update%d/%s/%d' % (it, fam, i), mat, out)
+                    out[tag + '/update%d/%s/%d#trace' % (it, fam, i)] = np.float64(np.trace(mat.astype(np.float64)))
+        out[tag + '/module_classes'] = np.array([m.__class__.__name__ for m in agent.optimizer.modules])
+    np.savez_compressed(os.path.join(HERE, 'kfac.npz'), **out)
+
+
+if __name__ == '__main__':
+    sys.path.insert(0, HERE)
+    main()

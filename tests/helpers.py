@@ -78,3 +78,48 @@ def golden_subset(G, prefix, arr):
     if prefix + '#full' in G.files:
         return G[prefix + '#full'].astype(np.float64), a.astype(np.float64)
     return G[prefix + '#sample'].astype(np.float64), a[::SAMPLE_STRIDE].astype(np.float64)
+
+
+KFAC_CASES = [('cnn', 'cnn', None, 6, 20, 32), ('mlp', 'mlp', 17, 6, 5, 16)]
+
+
+def unsplit_name(n):
+    """Parameter name after KFAC's split_bias (kfac.py:74-84) -> original state_dict name."""
+    return n.replace('.module.weight', '.weight').replace('.add_bias._bias', '.bias')
+
+
+def check_update_vector(G, prefix_fmt, names, get, tol=1e-3, what=''):
+    """KFAC-preconditioned update parity (north_star: 1e-3 relative).  The update is ONE vector over all
+    parameters; per-tensor errors are measured against max(tensor norm, 10% of the whole-update norm) so
+    that a tiny, ill-conditioned block (e.g. the critic head when the feature factor is rank deficient at
+    small B) is held to the vector-level bar rather than to its own near-zero norm."""
+    whole = np.sqrt(sum(float(G[prefix_fmt % n + '#norm']) ** 2 for n in names))
+    tot = 0.0
+    cnt = 0
+    for n in names:
+        gold, mine = golden_subset(G, prefix_fmt % n, get(n))
+        gn = float(G[prefix_fmt % n + '#norm'])
+        full = np.asarray(get(n)).size
+        frac = gold.size / full                      # sampled fraction of this tensor
+        err = np.linalg.norm(mine - gold)
+        ref_scale = max(gn, 0.1 * whole) * np.sqrt(frac)
+        assert err <= tol * ref_scale + 1e-12, '%s %s: err %g vs scale %g' % (what, n, err, ref_scale)
+        tot += err ** 2 / frac
+    assert np.sqrt(tot) <= tol * whole, '%s whole-update rel err %g' % (what, np.sqrt(tot) / whole)
+
+
+def update_vector_errors(G, prefix_fmt, names, get_mine, get_truth):
+    """Whole-update-vector relative errors (reference golden vs truth, mine vs truth, mine vs golden), estimated
+    on the golden's stored subset of every tensor (full tensors or strided samples, rescaled by the sampled
+    fraction)."""
+    e_ref = e_mine = e_mg = nt = 0.0
+    for n in names:
+        gold, mine = golden_subset(G, prefix_fmt % n, get_mine(n))
+        _, truth = golden_subset(G, prefix_fmt % n, get_truth(n))
+        frac = gold.size / float(np.asarray(get_mine(n)).size)
+        e_ref += np.sum((gold - truth) ** 2) / frac
+        e_mine += np.sum((mine - truth) ** 2) / frac
+        e_mg += np.sum((mine - gold) ** 2) / frac
+        nt += np.sum(truth ** 2) / frac
+    nt = max(nt, 1e-300)
+    return np.sqrt(e_ref / nt), np.sqrt(e_mine / nt), np.sqrt(e_mg / nt)

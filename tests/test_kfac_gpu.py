@@ -1,0 +1,189 @@
+"""GPU parity of the KFAC pieces and of the full ACKTR update (HIP path through the C-ABI)."""
+import ctypes
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import synth
+from helpers import KFAC_CASES, check_summary, golden, t, unsplit_name, update_vector_errors
+from oracle import kfac_ref
+from test_policy_gpu import Box, Discrete, make_policy, make_storage
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a = np.asarray(a, np.float64).reshape(-1)
+    b = np.asarray(b, np.float64).reshape(-1)
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
+
+
+@pytest.mark.parametrize('H,K,S,C,B', [(84, 8, 4, 4, 7), (20, 4, 2, 32, 9), (9, 3, 1, 64, 40)])
+def test_cov_a_conv_vs_oracle(H, K, S, C, B):
+    from a2c_ppo_acktr import _hip, ops
+    g = torch.Generator().manual_seed(H + B)
+    x = torch.rand(B, C, H, H, generator=g)
+    ref = kfac_ref.cov_a(x, 'conv', (K, K), S)
+    L = _hip.lib()
+    Kc = C * K * K
+    OH = (H - K) // S + 1
+    out = torch.empty(Kc, Kc, device='cuda')
+    ws = ops.workspace('cuda', L.acktr_kfac_cov_workspace_bytes(Kc, B * OH * OH), 'kfac')
+    xd = x.cuda()
+    rc = L.acktr_kfac_cov_a_conv_f32(_hip.dev_ptr(xd), None, B, C, H, H, K, K, S, 1.0 / (B * float(OH * OH) ** 2),
+                                     _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(), _hip.cur_stream())
+    _hip.check(rc, 'cov_a_conv')
+    assert rel(out.cpu().numpy(), ref.numpy()) < 2e-5
+    assert torch.equal(out, out.t()), 'factor must be exactly symmetric'
+
+
+@pytest.mark.parametrize('OC,SP,B', [(32, 400, 5), (64, 81, 33), (32, 49, 100)])
+def test_cov_g_conv_and_bias_vs_oracle(OC, SP, B):
+    from a2c_ppo_acktr import _hip, ops
+    g = torch.Generator().manual_seed(OC + SP)
+    side = int(round(SP ** 0.5))
+    dy = torch.randn(B, OC, side, side, generator=g) / B
+    L = _hip.lib()
+    out = torch.empty(OC, OC, device='cuda')
+    ws = ops.workspace('cuda', L.acktr_kfac_cov_workspace_bytes(OC, B * SP), 'kfac')
+    dyd = dy.cuda()
+    rc = L.acktr_kfac_cov_g_conv_f32(_hip.dev_ptr(dyd), B, OC, SP, float(SP) * B, _hip.dev_ptr(out), _hip.dev_ptr(ws),
+                                     ws.numel(), _hip.cur_stream())
+    _hip.check(rc, 'cov_g_conv')
+    assert rel(out.cpu().numpy(), kfac_ref.cov_g(dy, 'conv').numpy()) < 2e-5
+    ssum = torch.empty(B, OC, device='cuda')
+    _hip.check(L.acktr_spatial_sum_f32(_hip.dev_ptr(dyd), B * OC, SP, _hip.dev_ptr(ssum), _hip.cur_stream()), 'ssum')
+    _hip.check(L.acktr_kfac_cov_dense_f32(_hip.dev_ptr(ssum), OC, B, OC, float(B), _hip.dev_ptr(out), _hip.dev_ptr(ws),
+                                          ws.numel(), _hip.cur_stream()), 'cov_dense')
+    assert rel(out.cpu().numpy(), kfac_ref.cov_g(dy, 'bias').numpy()) < 2e-5
+
+
+def test_running_stat_bit_exact():
+    from a2c_ppo_acktr import _hip
+    g = torch.Generator().manual_seed(1)
+    m = torch.randn(1000, generator=g)
+    x = torch.randn(1000, generator=g)
+    ref = m.clone()
+    kfac_ref.running_stat(x, ref, 0.99)
+    md = m.cuda()
+    _hip.check(_hip.lib().acktr_kfac_running_stat_f32(_hip.dev_ptr(md), _hip.dev_ptr(x.cuda()), 1000, 0.99, 0,
+                                                      _hip.cur_stream()), 'rs')
+    assert torch.equal(md.cpu(), ref)
+    ref0 = x.clone()
+    kfac_ref.running_stat(x, ref0, 0.99)
+    _hip.check(_hip.lib().acktr_kfac_running_stat_f32(_hip.dev_ptr(md), _hip.dev_ptr(x.cuda()), 1000, 0.99, 1,
+                                                      _hip.cur_stream()), 'rs')
+    assert torch.equal(md.cpu(), ref0)
+
+
+def _psd(n, rank, gen):
+    a = torch.randn(rank, n, generator=gen)
+    return (a.t() @ a / rank).contiguous()
+
+
+@pytest.mark.parametrize('sizes', [[1, 6, 32, 64, 7, 33], [128, 100, 1, 2]])
+def test_jacobi_batched(sizes):
+    """Eigenvalues ascending, thresholded, Q Lambda Q^T reconstructs the input, rows orthonormal (never compare Q)."""
+    from a2c_ppo_acktr import _hip
+    from a2c_ppo_acktr.algo.kfac import _JacobiDesc
+    g = torch.Generator().manual_seed(sum(sizes))
+    mats = [_psd(n, max(1, n // 2) if i % 2 else n + 3, g).cuda() for i, n in enumerate(sizes)]
+    ds = [torch.empty(n, device='cuda') for n in sizes]
+    qts = [torch.empty(n, n, device='cuda') for n in sizes]
+    arr = (_JacobiDesc * len(sizes))(*[_JacobiDesc(m.data_ptr(), d.data_ptr(), q.data_ptr(), n)
+                                        for m, d, q, n in zip(mats, ds, qts, sizes)])
+    descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    rc = _hip.lib().acktr_sym_eig_jacobi_batched_f32(_hip.dev_ptr(descs), len(sizes), max(sizes), 1e-6,
+                                                     _hip.cur_stream())
+    _hip.check(rc, 'jacobi')
+    for m, d, q, n in zip(mats, ds, qts, sizes):
+        A = m.cpu().double().numpy()
+        w = np.linalg.eigvalsh(A)
+        dd = d.cpu().double().numpy()
+        Q = q.cpu().double().numpy().T
+        assert np.all(np.diff(dd) >= -1e-7 * max(w.max(), 1e-6)), 'ascending'
+        w_thr = np.where(w > 1e-6, w, 0.0)
+        assert np.abs(dd - w_thr).max() <= 2e-6 * max(w.max(), 1.0) + 2e-6
+        assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-5
+        dd_raw = np.where(dd > 0, dd, 0.0)
+        recon = Q @ np.diag(dd_raw) @ Q.T
+        assert np.linalg.norm(recon - A) <= 1e-5 * np.linalg.norm(A) + 2e-6 * n
+
+
+@pytest.mark.parametrize('n', [256, 576, 1568])
+def test_rocsolver_eig(n):
+    from a2c_ppo_acktr import _hip
+    g = torch.Generator().manual_seed(n)
+    A = _psd(n, n // 3, g)
+    q = A.clone().cuda()
+    d = torch.empty(n, device='cuda')
+    e = torch.empty(n, device='cuda')
+    info = torch.zeros(1, dtype=torch.int32, device='cuda')
+    rc = _hip.lib().acktr_sym_eig_rocsolver_f32(_hip.dev_ptr(q), n, _hip.dev_ptr(d), _hip.dev_ptr(e),
+                                                _hip.dev_ptr(info, torch.int32), 1e-6, _hip.cur_stream())
+    _hip.check(rc, 'rocsolver')
+    assert int(info.item()) == 0
+    w = np.linalg.eigvalsh(A.double().numpy())
+    dd = d.cpu().double().numpy()
+    assert np.abs(dd - np.where(w > 1e-6, w, 0.0)).max() <= 1e-5 * w.max()
+    Q = q.cpu().double().numpy().T            # rows of qt are eigenvectors
+    assert np.abs(Q.T @ Q - np.eye(n)).max() < 1e-4
+    assert np.linalg.norm(Q @ np.diag(dd) @ Q.T - A.double().numpy()) <= 1e-4 * np.linalg.norm(A.numpy())
+
+
+@pytest.mark.parametrize('OUT,IN', [(32, 256), (512, 1568), (6, 512), (64, 1), (1, 512)])
+def test_precondition_vs_torch(OUT, IN):
+    from a2c_ppo_acktr import _hip
+    g = torch.Generator().manual_seed(OUT * 7 + IN)
+    Ag, Aa = _psd(OUT, OUT + 5, g), _psd(IN, IN + 5, g)
+    dg, Qg = torch.linalg.eigh(Ag)
+    da, Qa = torch.linalg.eigh(Aa)
+    G = torch.randn(OUT, IN, generator=g)
+    ref = Qg @ ((Qg.t() @ G @ Qa) / (dg.unsqueeze(1) * da.unsqueeze(0) + 0.01)) @ Qa.t()
+    dev = lambda x: x.contiguous().cuda()
+    qtg, qta, dgd, dad, Gd = dev(Qg.t()), dev(Qa.t()), dev(dg), dev(da), dev(G)
+    t1, t2, v = torch.empty(OUT * IN, device='cuda'), torch.empty(OUT * IN, device='cuda'), torch.empty(OUT, IN, device='cuda')
+    rc = _hip.lib().acktr_kfac_precondition_f32(_hip.dev_ptr(Gd), _hip.dev_ptr(qtg), _hip.dev_ptr(dgd), _hip.dev_ptr(qta),
+                                                _hip.dev_ptr(dad), OUT, IN, 0.01, _hip.dev_ptr(t1), _hip.dev_ptr(t2),
+                                                _hip.dev_ptr(v), _hip.cur_stream())
+    _hip.check(rc, 'precondition')
+    assert rel(v.cpu().numpy(), ref.numpy()) < 5e-5
+
+
+@pytest.mark.parametrize('ci', range(len(KFAC_CASES)))
+def test_acktr_update_vs_reference(ci):
+    """Full A2C_ACKTR(acktr=True).update x3 (eigendecompositions at steps 0 and 2).  Losses, factors and
+    parameters against the reference goldens; the preconditioned update against the fp64 truth with the
+    reference's own fp32 error as yardstick (see tests/test_oracle_kfac.py for why)."""
+    from a2c_ppo_acktr import algo
+    from test_oracle_kfac import fp64_truth
+    tag, kind, od, A, T, N = KFAC_CASES[ci]
+    G = golden('kfac')
+    pol = make_policy(kind, od, A, 90 + ci)
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=820 + ci)
+    rs = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
+    rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
+    truth = fp64_truth(ci)
+    agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
+    agent.optimizer.Tf = 2
+    names = [str(n) for n in G[tag + '/param_names']]
+    assert [n for n, _ in pol.named_parameters()] == names, 'split_bias must rename parameters like the reference'
+    assert [m.__class__.__name__ for m in agent.optimizer.modules] == [str(c) for c in G[tag + '/module_classes']]
+    params = dict(pol.named_parameters())
+    for it in range(3):
+        torch.manual_seed(555 + it)
+        res = agent.update(rs)
+        np.testing.assert_allclose(np.array(res), G[tag + '/update%d/losses' % it], rtol=1e-4, atol=1e-6)
+        for i, m in enumerate(agent.optimizer.modules):
+            check_summary(G, tag + '/update%d/m_aa/%d' % (it, i), agent.optimizer.m_aa[m].cpu().numpy(), 1e-4, tag)
+            check_summary(G, tag + '/update%d/m_gg/%d' % (it, i), agent.optimizer.m_gg[m].cpu().numpy(), 1e-4, tag)
+        e_ref, e_mine, e_mg = update_vector_errors(G, tag + '/update%d/kfgrad/' % it + '%s', names,
+                                                   lambda n: params[n].grad.detach().cpu().numpy(),
+                                                   lambda n: truth[it][unsplit_name(n)])
+        print(tag, 'update', it, 'e_ref %.3g e_mine %.3g mine-vs-golden %.3g' % (e_ref, e_mine, e_mg))
+        assert e_mine <= 2.0 * e_ref + 1e-3, (it, e_ref, e_mine, e_mg)
+        for n in names:
+            check_summary(G, tag + '/update%d/param/%s' % (it, n), params[n].detach().cpu().numpy(), 1e-4, tag)

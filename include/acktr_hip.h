@@ -179,9 +179,10 @@ int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, float alpha
                              long workspace_bytes, void* stream);
 /* out[row] = sum_sp g[row, sp] -- the AddBias branch of compute_cov_g, kfac.py:59-61. */
 int acktr_spatial_sum_f32(const float* g, int rows, int SP, float* out, void* stream);
-/* update_running_stat -- kfac.py:67-71: m = ((m * d/(1-d)) + x) * (1-d), three roundings; init != 0 first sets
- * m = x (kfac.py:156-157,174-175). */
-int acktr_kfac_running_stat_f32(float* m, const float* x, long n, float stat_decay, int init, void* stream);
+/* update_running_stat -- kfac.py:67-71: m = ((m * c1) + x) * c2, three roundings, with c1 = (float)(d/(1-d)) and
+ * c2 = (float)(1-d) evaluated by the host in double like the python scalars; init != 0 first sets m = x
+ * (kfac.py:156-157,174-175). */
+int acktr_kfac_running_stat_f32(float* m, const float* x, long n, float c1, float c2, int init, void* stream);
 
 /* torch.symeig(m, eigenvectors=True) + `d *= (d > thresh)` -- kfac.py:208-214.  Eigenvalues ascending;
  * eigenvectors are returned as the ROWS of qt (qt = Q^T).

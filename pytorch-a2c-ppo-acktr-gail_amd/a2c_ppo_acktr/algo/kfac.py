@@ -286,8 +286,9 @@ class KFACOptimizer(optim.Optimizer):
         dp.all_reduce_sum_(self.gg_sample)
         init = 1 if self.steps == 0 else 0
         for run, smp in ((self.aa_run, self.aa_sample), (self.gg_run, self.gg_sample)):
-            rc = L.acktr_kfac_running_stat_f32(_hip.dev_ptr(run), _hip.dev_ptr(smp), run.numel(), self.stat_decay, init,
-                                               stream)
+            d = float(self.stat_decay)
+            rc = L.acktr_kfac_running_stat_f32(_hip.dev_ptr(run), _hip.dev_ptr(smp), run.numel(), d / (1 - d), 1 - d,
+                                               init, stream)
             _hip.check(rc, 'acktr_kfac_running_stat_f32')
 
     # ------------------------------------------------------------------ eigendecompositions (kfac.py:205-214)

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void jacobi_batched_kernel(const JacobiDesc* d
     fro = block_sum(fro, red);
     if (tid == 0) red[0] = fro;
     __syncthreads();
-    const float tiny = 1e-8f * sqrtf(red[0]) + 1e-37f;
+    const float tiny = 1e-7f * sqrtf(red[0]) + 1e-37f;   // ~fp32 eps * ||A||_F: below this an entry is rounding noise
     __syncthreads();
     const int m = (n + 1) & ~1;          // even number of players (one dummy if n is odd)
     const int half = m / 2;
@@ -186,13 +186,16 @@ __global__ __launch_bounds__(256) void jacobi_batched_kernel(const JacobiDesc* d
             rank += (dj < di || (dj == di && j < i)) ? 1 : 0;
         }
         de.d[rank] = di > thresh ? di : 0.f;
-        V[n * P + i] = (float)rank;       // spare row of V (pitch gives one extra column per row, use last row slot)
+        V[n * P + i] = (float)rank;       // spare row n of V (the LDS carve has room for n+1 rows)
+        float nrm = 0.f;                  // re-normalise eigenvector i: removes the c^2+s^2 rounding drift
+        for (int r = 0; r < n; ++r) nrm += V[r * P + i] * V[r * P + i];
+        cs[i >> 1][i & 1] = rsqrtf(nrm);
     }
     __syncthreads();
     for (int w = tid; w < n * n; w += 256) {
         const int col = w / n, i = w % n;         // eigenvector = column `col` of V
         const int rank = (int)V[n * P + col];
-        de.qt[(long)rank * n + i] = V[i * P + col];
+        de.qt[(long)rank * n + i] = V[i * P + col] * cs[col >> 1][col & 1];
     }
 }
 
@@ -311,11 +314,9 @@ extern "C" int acktr_spatial_sum_f32(const float* g, int rows, int SP, float* ou
     return 0;
 }
 
-extern "C" int acktr_kfac_running_stat_f32(float* m, const float* x, long n, float stat_decay, int init, void* stream) {
+extern "C" int acktr_kfac_running_stat_f32(float* m, const float* x, long n, float c1, float c2, int init,
+                                           void* stream) {
     ACKTR_ARG(m && x && n > 0, "kfac_running_stat: bad arguments");
-    // python: momentum/(1-momentum) and (1-momentum) are doubles rounded to fp32 when applied to the fp32 tensor
-    const float c1 = (float)((double)stat_decay / (1.0 - (double)stat_decay));
-    const float c2 = (float)(1.0 - (double)stat_decay);
     int nb = cdiv(n, 1024);
     if (nb > 2048) nb = 2048;
     hipLaunchKernelGGL(running_stat_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, m, x, n, c1, c2, init);

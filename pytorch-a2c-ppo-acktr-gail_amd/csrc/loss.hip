@@ -100,8 +100,33 @@ __device__ __forceinline__ LossTerms ppo_terms(float logp, float v, float old_lo
     return t;
 }
 
+// Per-sample loss summands and their derivatives w.r.t. logp and v (before the 1/B and value_coef factors).
+// ALGO is a template parameter on purpose: it is launch-uniform, and with a run-time `algo` hipcc (ROCm 7.2)
+// mis-structurises the three-way branch -- the Fisher lanes never execute `t.al = -logp` (seen in the ISA).
+template <int ALGO>
+__device__ __forceinline__ LossTerms algo_terms(float logp, float v, float old_logp, float old_v, float ret,
+                                                float advn, float clip, int clipped_vl) {
+    if constexpr (ALGO == 0) return ppo_terms(logp, v, old_logp, old_v, ret, advn, clip, clipped_vl);
+    LossTerms t;
+    if constexpr (ALGO == 1) {            // a2c_acktr.py:48-51: adv = R - v; VL = mean(adv^2); AL = -mean(adv.detach()*logp)
+        const float adv = ret - v;
+        t.vl = adv * adv;
+        t.al = -(adv * logp);
+        t.dlogp = -adv;
+        t.dv = -2.f * adv;
+    } else {                    // a2c_acktr.py:56-65: pg_fisher = -mean(logp); vf_fisher = -mean((v-(v+noise).detach())^2)
+        const float sample = v + advn;
+        const float diff = v - sample;
+        t.vl = -(diff * diff);
+        t.al = -logp;
+        t.dlogp = -1.0f;
+        t.dv = -2.f * diff;
+    }
+    return t;
+}
+
 // One kernel for all (algo, dist) pairs.  algo: 0 PPO, 1 A2C, 2 ACKTR Fisher.
-template <int DIST>
+template <int DIST, int ALGO>
 __global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_args a, float* partial) {
     __shared__ float sm[16];
     const int b = blockIdx.x * LOSS_THREADS + threadIdx.x;
@@ -126,28 +151,17 @@ __global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_ar
             d = gaussian_eval(din, a.logstd, act_f, A);
         }
         if (a.logp_out) a.logp_out[b] = d.logp;
-        float dlogp, dv;
-        if (a.algo == 0) {
-            const LossTerms t = ppo_terms(d.logp, v, a.old_logp[src], a.old_values[src], a.returns[src], a.adv[src],
-                                          a.clip, a.use_clipped_value_loss);
-            vl = t.vl; al = t.al;
-            dlogp = t.dlogp * a.inv_batch;
-            dv = a.value_coef * t.dv * a.inv_batch;
-        } else if (a.algo == 1) {         // a2c_acktr.py:48-51: adv = R - v; VL = mean(adv^2); AL = -mean(adv.detach()*logp)
-            const float adv = a.returns[src] - v;
-            vl = adv * adv; al = -(adv * d.logp);
-            dlogp = -adv * a.inv_batch;
-            dv = a.value_coef * (-2.f * adv) * a.inv_batch;
-        } else {                          // a2c_acktr.py:56-65: pg_fisher = -mean(logp); vf_fisher = -mean((v-(v+noise))^2)
-            const float sample = v + a.adv[src];      // `adv` carries the CPU-drawn noise (F7)
-            const float diff = v - sample;
-            vl = -(diff * diff); al = -d.logp;
-            dlogp = -a.inv_batch;
-            dv = -2.f * diff * a.inv_batch;
-        }
+        const float o_logp = a.old_logp ? a.old_logp[src] : 0.f;
+        const float o_val = a.old_values ? a.old_values[src] : 0.f;
+        const float ret = a.returns ? a.returns[src] : 0.f;
+        const float advn = a.adv ? a.adv[src] : 0.f;          // advantage (PPO) or Fisher noise (ACKTR)
+        const LossTerms t = algo_terms<ALGO>(d.logp, v, o_logp, o_val, ret, advn, a.clip, a.use_clipped_value_loss);
+        vl = t.vl; al = t.al;
+        const float dlogp = t.dlogp * a.inv_batch;
+        const float dv = ((ALGO == 2) ? 1.0f : a.value_coef) * t.dv * a.inv_batch;
         en = d.ent;
         // entropy enters the loss as  -entropy_coef * mean(entropy)   (not in the Fisher loss)
-        const float dent = (a.algo == 2) ? 0.f : -a.entropy_coef * a.inv_batch;
+        const float dent = (ALGO == 2) ? 0.f : -a.entropy_coef * a.inv_batch;
         if (a.dvalues) a.dvalues[(long)b * a.ld_dvalues] = dv;
         float* dd = a.ddist + (long)b * a.ld_ddist;
         if (DIST == 0) {
@@ -262,10 +276,13 @@ extern "C" int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     const int nblk = cdiv(a.B, LOSS_THREADS);
     float* partial = (float*)a.workspace;
-    if (a.dist == 0)
-        hipLaunchKernelGGL((policy_loss_kernel<0>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial);
-    else
-        hipLaunchKernelGGL((policy_loss_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial);
+#define LAUNCH_LOSS(D, G) hipLaunchKernelGGL((policy_loss_kernel<D, G>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial)
+    if (a.dist == 0) {
+        if (a.algo == 0) LAUNCH_LOSS(0, 0); else if (a.algo == 1) LAUNCH_LOSS(0, 1); else LAUNCH_LOSS(0, 2);
+    } else {
+        if (a.algo == 0) LAUNCH_LOSS(1, 0); else if (a.algo == 1) LAUNCH_LOSS(1, 1); else LAUNCH_LOSS(1, 2);
+    }
+#undef LAUNCH_LOSS
     ACKTR_LAUNCH_CHECK();
     const int NP = 3 + (a.dist == 1 ? a.A : 0);
     hipLaunchKernelGGL(policy_loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nblk, NP, a.inv_batch, a.loss_acc,

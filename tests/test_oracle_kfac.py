@@ -41,7 +41,9 @@ def fp64_truth(ci, n_updates=3):
         torch.manual_seed(555 + it)
         noise = torch.randn(T, N, 1).double()
         _, info = kfac_ref.acktr_update(P64, st, ro64, 0.5, 0.01, noise=noise)
-        out.append({k: v.numpy().copy() for k, v in info['grads'].items()})
+        d = {k: v.numpy().copy() for k, v in info['grads'].items()}
+        d.update({'param:' + k: v.detach().numpy().copy() for k, v in P64.items()})
+        out.append(d)
     return out
 
 
@@ -67,5 +69,7 @@ def test_acktr_update_oracle_vs_reference(ci):
                                                    lambda n: info['grads'][unsplit_name(n)].numpy(),
                                                    lambda n: truth[it][unsplit_name(n)])
         assert e_mine <= 2.0 * e_ref + 1e-3, (it, e_ref, e_mine, e_mg)
-        for n in names:
-            check_summary(G, tag + '/update%d/param/%s' % (it, n), P[unsplit_name(n)].detach().numpy(), 1e-4, tag)
+        p_ref, p_mine, _ = update_vector_errors(G, tag + '/update%d/param/' % it + '%s', names,
+                                                lambda n: P[unsplit_name(n)].detach().numpy(),
+                                                lambda n: truth[it]['param:' + unsplit_name(n)])
+        assert p_mine <= 2.0 * p_ref + 1e-4, (it, p_ref, p_mine)

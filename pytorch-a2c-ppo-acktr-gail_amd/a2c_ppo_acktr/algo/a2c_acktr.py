@@ -59,6 +59,8 @@ class A2C_ACKTR():
         else:
             self.optimizer = _FlatRMSprop(actor_critic, lr, eps=eps, alpha=alpha)
         self.dp = DataParallel()
+        if acktr:
+            self.optimizer.dp = self.dp
 
     def update(self, rollouts):
         ac = self.actor_critic

@@ -17,6 +17,7 @@ import torch.nn as nn
 import torch.optim as optim
 
 from .. import _hip, engine, ops
+from ..parallel import DataParallel, assign_eig_owners
 from ..utils import AddBias
 
 f32 = torch.float32
@@ -102,6 +103,7 @@ class KFACOptimizer(optim.Optimizer):
         self.sgd_lr = self.lr * (1 - self.momentum)
         self._mom_buf = None
         self._ready_device = None
+        self.dp = DataParallel()          # replaced by A2C_ACKTR with its own context
 
     # ------------------------------------------------------------------ module discovery (kfac.py:179-188)
     def _prepare_model(self):
@@ -165,24 +167,31 @@ class KFACOptimizer(optim.Optimizer):
         nmax = max(max(m.na, m.ng) for m in self._mods)
         self.e_work = z(nmax)
         self.info = torch.zeros(1, dtype=torch.int32, device=dev)
-        # batched-Jacobi descriptors for every small factor (built once: pointers are stable)
+        # eigendecomposition work list: (run bucket, qt bucket, d bucket, offset, d offset, n), one per factor,
+        # sharded layer-wise over the data-parallel ranks (greedy by n^3) -- SURVEY 8(e)
         L = _hip.lib()
         jmax = L.acktr_jacobi_max_n()
+        work = []
+        for m in self._mods:
+            work.append((self.aa_run, self.qt_a, self.d_a_flat, m.oa, m.da_off, m.na))
+            work.append((self.gg_run, self.qt_g, self.d_g_flat, m.og, m.dg_off, m.ng))
+        self._eig_work = work
+        self._eig_owner = assign_eig_owners([w[5] for w in work], self.dp.world)
         descs, self._big = [], []
         self._jac_max = 1
-        for m in self._mods:
-            for (run, qt, dfl, off, doff, n) in ((self.aa_run, self.qt_a, self.d_a_flat, m.oa, m.da_off, m.na),
-                                                 (self.gg_run, self.qt_g, self.d_g_flat, m.og, m.dg_off, m.ng)):
-                if n <= jmax:
-                    d = _JacobiDesc(run.data_ptr() + 4 * off, dfl.data_ptr() + 4 * doff, qt.data_ptr() + 4 * off, n)
-                    descs.append(d)
-                    self._jac_max = max(self._jac_max, n)
-                else:
-                    self._big.append((run, qt, dfl, off, doff, n))
-        arr = (_JacobiDesc * len(descs))(*descs)
-        raw = bytes(arr)
-        self._jac_descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        for w, own in zip(work, self._eig_owner):
+            if own != self.dp.rank:
+                continue
+            run, qt, dfl, off, doff, n = w
+            if n <= jmax:       # batched Jacobi descriptors (built once: pointers are stable)
+                descs.append(_JacobiDesc(run.data_ptr() + 4 * off, dfl.data_ptr() + 4 * doff, qt.data_ptr() + 4 * off, n))
+                self._jac_max = max(self._jac_max, n)
+            else:
+                self._big.append(w)
         self._jac_count = len(descs)
+        if descs:
+            arr = (_JacobiDesc * len(descs))(*descs)
+            self._jac_descs = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
         self._ready_device = dev
 
     # ------------------------------------------------------------------ statistics (kfac.py:144-177)
@@ -307,6 +316,15 @@ class KFACOptimizer(optim.Optimizer):
                                                _hip.dev_ptr(self.e_work), _hip.dev_ptr(self.info, torch.int32), 1e-6,
                                                stream)
             _hip.check(rc, 'acktr_sym_eig_rocsolver_f32')
+        if self.dp.active:
+            # every factor was decomposed by exactly one rank: zero the slots this rank does not own and SUM
+            # all-reduce the four flat buckets (= a broadcast from each owner in one collective per bucket)
+            for (run, qt, dfl, off, doff, n), own in zip(self._eig_work, self._eig_owner):
+                if own != self.dp.rank:
+                    qt[off:off + n * n].zero_()
+                    dfl[doff:doff + n].zero_()
+            for buf in (self.qt_a, self.qt_g, self.d_a_flat, self.d_g_flat):
+                self.dp.all_reduce_sum_(buf)
 
     # ------------------------------------------------------------------ step (kfac.py:190-242)
     def step(self):

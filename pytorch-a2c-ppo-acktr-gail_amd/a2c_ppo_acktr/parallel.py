@@ -45,3 +45,17 @@ class DataParallel(object):
         if self.active:
             dist.broadcast(t, src=src, group=self.group)
         return t
+
+
+def assign_eig_owners(sizes, world):
+    """Layer-wise sharding of the KFAC eigendecompositions (kfac.py:205-214) over ranks: greedy
+    longest-processing-time on an n^3 cost model.  Deterministic, identical on every rank.
+    Returns a list owner[i] in [0, world)."""
+    order = sorted(range(len(sizes)), key=lambda i: (-sizes[i], i))
+    load = [0.0] * world
+    owner = [0] * len(sizes)
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        owner[i] = r
+        load[r] += float(sizes[i]) ** 3
+    return owner

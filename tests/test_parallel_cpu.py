@@ -1,0 +1,114 @@
+"""CPU (gloo, world_size 2): the data-parallel sharding math of a2c_ppo_acktr/parallel.py.
+
+The HIP engine cannot run here, so the per-rank "local gradient" is produced by the CPU oracle; what is
+under test is the host logic that surrounds it on the GPU path: identical permutations on every rank,
+contiguous balanced shards, 1/B_global loss scaling, SUM all-reduce of one flat bucket, KFAC factor
+scalings with the global batch, and the layer-wise eigensolve assignment."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import synth
+from helpers import params_torch, t
+from oracle import algo_ref, kfac_ref, policy_ref
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from a2c_ppo_acktr.parallel import DataParallel
+    dp = DataParallel()
+    assert dp.active and dp.world == world and dp.rank == rank
+    B, od, A = 50, 11, 3                       # B not divisible by world*anything special: unequal shards
+    P = params_torch(synth.make_params(policy_ref.mlp_param_shapes(od, 64, A), 5))
+    ro = synth.make_rollouts(1, B, (od,), 'box', A, salt=77)
+    obs, act = t(ro['obs'][0]), t(ro['actions'][0])
+    vp, olp = t(ro['value_preds'][0]), t(ro['action_log_probs'][0])
+    ret, adv = t(synth.normalish((B, 1), 1)), t(synth.normalish((B, 1), 2))
+    torch.manual_seed(123)                     # same seed on every rank -> same permutation (F7)
+    perm = torch.randperm(B)
+    idx = dp.shard(perm)
+    lo, hi = dp.bounds(B)
+    assert idx.numel() == hi - lo
+    # local loss terms scaled by 1/B_global (what the fused loss kernel does with inv_batch)
+    for v in P.values():
+        v.requires_grad_(True)
+    values, logp, ent = policy_ref.evaluate_actions(P, obs[idx], act[idx])
+    ratio = torch.exp(logp - olp[idx])
+    s1, s2 = ratio * adv[idx], torch.clamp(ratio, 0.8, 1.2) * adv[idx]
+    al = -torch.min(s1, s2).sum() / B
+    vpc = vp[idx] + (values - vp[idx]).clamp(-0.2, 0.2)
+    vl = 0.5 * torch.max((values - ret[idx]).pow(2), (vpc - ret[idx]).pow(2)).sum() / B
+    en = ent * idx.numel() / B                 # entropy mean over the shard -> contribution to the global mean
+    loss = vl * 0.5 + al - en * 0.01
+    grads = torch.autograd.grad(loss, list(P.values()))
+    flat = torch.cat([g.reshape(-1) for g in grads])
+    dp.all_reduce_sum_(flat)
+    # KFAC factor partial sums with GLOBAL scalings
+    g_local = torch.randn(B, 7, generator=torch.Generator().manual_seed(9))[perm][lo:hi]
+    gg = (float(B) * g_local.t() @ g_local)    # alpha = B_global, summed over ranks
+    dp.all_reduce_sum_(gg)
+    if rank == 0:
+        torch.save({'flat': flat, 'gg': gg, 'perm': perm}, os.path.join(out_dir, 'dp.pt'))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_gradient_and_factor_sharding(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = torch.load(os.path.join(str(tmp_path), 'dp.pt'))
+    B, od, A = 50, 11, 3
+    P = params_torch(synth.make_params(policy_ref.mlp_param_shapes(od, 64, A), 5))
+    ro = synth.make_rollouts(1, B, (od,), 'box', A, salt=77)
+    perm = res['perm']
+    sel = lambda x: t(x)[perm]
+    losses, G = algo_ref.ppo_minibatch_grads(P, sel(ro['obs'][0]), sel(ro['actions'][0]), sel(ro['value_preds'][0]),
+                                             sel(synth.normalish((B, 1), 1)), sel(ro['action_log_probs'][0]),
+                                             sel(synth.normalish((B, 1), 2)), 0.2, 0.5, 0.01)
+    full = torch.cat([g.reshape(-1) for g in G.values()])
+    assert float((res['flat'] - full).norm() / full.norm()) < 1e-5
+    g_all = torch.randn(B, 7, generator=torch.Generator().manual_seed(9))[perm]
+    assert float((res['gg'] - kfac_ref.cov_g(g_all, 'linear')).norm() / kfac_ref.cov_g(g_all, 'linear').norm()) < 1e-5
+
+
+def test_shard_bounds_partition():
+    from a2c_ppo_acktr.parallel import DataParallel
+    dp = DataParallel()
+    assert not dp.active and dp.shard(torch.arange(5)).numel() == 5
+    for world in (2, 3, 8):
+        for n in (1, 7, 64, 1023):
+            cover = []
+            for r in range(world):
+                dp.world, dp.rank = world, r
+                lo, hi = dp.bounds(n)
+                cover += list(range(lo, hi))
+            assert cover == list(range(n))
+
+
+def test_eig_owner_assignment_balanced_and_deterministic():
+    from a2c_ppo_acktr.parallel import assign_eig_owners
+    sizes = [256, 32, 1, 32, 512, 64, 1, 64, 576, 32, 1, 32, 1568, 512, 1, 512, 512, 1, 1, 1, 512, 6, 1, 6]
+    for world in (1, 2, 4, 8):
+        own = assign_eig_owners(sizes, world)
+        assert own == assign_eig_owners(list(sizes), world)
+        assert set(own) <= set(range(world))
+        loads = [sum(float(s) ** 3 for s, o in zip(sizes, own) if o == r) for r in range(world)]
+        crit = max(float(s) ** 3 for s in sizes)
+        assert max(loads) <= max(crit, sum(loads) / world) * 1.34 + 1    # LPT bound (4/3) against the 1568 factor
+    assert assign_eig_owners(sizes, 8)[12] != assign_eig_owners(sizes, 8)[8]   # 1568 and 576 on different ranks

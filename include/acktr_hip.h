@@ -152,6 +152,11 @@ long acktr_optim_workspace_bytes(void);
 int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_grad_norm,
                         float step_size, float beta1, float beta2, float eps, float bias_correction2_sqrt,
                         float* total_norm_out, void* workspace, void* stream);
+/* Same update with the step-dependent scalars taken from DEVICE memory so the launch sequence can be captured in a
+ * hipGraph and replayed: hyper_dev = {lr, beta1, beta2, eps}; *step_dev is incremented first and used as Adam's t
+ * (bias corrections evaluated in double on the device).  No counterpart in the reference (host loop there). */
+int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_grad_norm,
+                            const float* hyper_dev, int* step_dev, void* workspace, void* stream);
 /* clip_grad_norm_ + optim.RMSprop.step -- algo/a2c_acktr.py:74-78 (torch/optim/rmsprop.py:316-339). */
 int acktr_clip_rmsprop_f32(float* params, float* grads, float* square_avg, long n, float max_grad_norm, float lr,
                            float alpha, float eps, float* total_norm_out, void* workspace, void* stream);

@@ -58,6 +58,7 @@ _PROTOS = {
     'acktr_dist_bwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_p]),
     'acktr_optim_workspace_bytes': (c_l, []),
     'acktr_clip_adam_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
+    'acktr_clip_adam_dev_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p]),
     'acktr_clip_rmsprop_f32': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_sgd_momentum_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_i, c_p]),
     'acktr_kfac_cov_workspace_bytes': (c_l, [c_i, c_l]),

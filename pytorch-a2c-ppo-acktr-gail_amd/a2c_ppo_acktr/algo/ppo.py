@@ -6,6 +6,8 @@ categorical/gaussian + clipped-surrogate loss kernel that also emits the backwar
 into the flat gradient bucket -> [RCCL all-reduce] -> clip-norm + Adam in two launches.  Nothing syncs
 with the host until the three averaged losses are read back once at the end of `update`.
 """
+import os
+
 import torch
 
 from .. import _hip, engine, ops
@@ -14,7 +16,9 @@ from ..parallel import DataParallel
 
 class _FlatAdam(object):
     """optim.Adam over the policy's flat buffer (torch/optim/adam.py:529-547 single-tensor math).
-    Exposes `param_groups` so update_linear_schedule (utils.py:46-50) works as in the reference."""
+    Exposes `param_groups` so update_linear_schedule (utils.py:46-50) works as in the reference.
+    The step counter and {lr, betas, eps} live in device memory, so the same launch sequence serves eager
+    calls and hipGraph replays."""
 
     def __init__(self, policy, lr, eps, betas=(0.9, 0.999)):
         self.policy = policy
@@ -22,32 +26,43 @@ class _FlatAdam(object):
         self.step_count = 0
         self.exp_avg = None
         self.exp_avg_sq = None
+        self._hyper_host = None
 
     def _state(self):
         flat = self.policy.flat_params
         if self.exp_avg is None or self.exp_avg.device != flat.device or self.exp_avg.numel() != flat.numel():
             self.exp_avg = torch.zeros_like(flat)
             self.exp_avg_sq = torch.zeros_like(flat)
+            self.step_dev = torch.full((1,), self.step_count, dtype=torch.int32, device=flat.device)
+            self.hyper_dev = torch.zeros(4, dtype=torch.float32, device=flat.device)
+            self._hyper_host = None
+        g = self.param_groups[0]
+        hyper = (float(g['lr']), float(g['betas'][0]), float(g['betas'][1]), float(g['eps']))
+        if hyper != self._hyper_host:                      # rare: construction and lr-schedule changes
+            self.hyper_dev.copy_(torch.tensor(hyper, dtype=torch.float32))
+            self._hyper_host = hyper
 
     def zero_grad(self, set_to_none=False):
         self.policy.flat_grads.zero_()
 
-    def step(self, max_grad_norm=None):
-        """clip_grad_norm_(max_grad_norm) (if given) + Adam step on the flat buffers."""
+    def prepare(self):
+        """Host-side refresh of the device hyper-parameters; call outside graph capture."""
         self._state()
-        g = self.param_groups[0]
+
+    def step(self, max_grad_norm=None, capturing=False):
+        """clip_grad_norm_(max_grad_norm) (if given) + Adam step on the flat buffers."""
+        if not capturing:
+            self._state()
         self.step_count += 1
-        b1, b2 = g['betas']
-        bc1 = 1 - b1 ** self.step_count
-        bc2 = 1 - b2 ** self.step_count
         flat, gflat = self.policy.flat_params, self.policy.flat_grads
         L = _hip.lib()
         ws = ops.workspace(flat.device, L.acktr_optim_workspace_bytes(), 'optim')
-        rc = L.acktr_clip_adam_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
-                                   _hip.dev_ptr(self.exp_avg_sq), flat.numel(),
-                                   float(max_grad_norm) if max_grad_norm else 0.0, g['lr'] / bc1, b1, b2, g['eps'],
-                                   bc2 ** 0.5, None, _hip.dev_ptr(ws), _hip.cur_stream(flat.device))
-        _hip.check(rc, 'acktr_clip_adam_f32')
+        rc = L.acktr_clip_adam_dev_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
+                                       _hip.dev_ptr(self.exp_avg_sq), flat.numel(),
+                                       float(max_grad_norm) if max_grad_norm else 0.0, _hip.dev_ptr(self.hyper_dev),
+                                       _hip.dev_ptr(self.step_dev, torch.int32), _hip.dev_ptr(ws),
+                                       _hip.cur_stream(flat.device))
+        _hip.check(rc, 'acktr_clip_adam_dev_f32')
 
 
 class PPO():
@@ -77,6 +92,22 @@ class PPO():
 
         self.optimizer = _FlatAdam(actor_critic, lr=lr, eps=eps)
         self.dp = DataParallel()
+        # hipGraph replay of the minibatch step (launch-bound otherwise): captured at the second update() that
+        # sees the same storage / shapes; ACKTR_HIP_GRAPH=0 disables it.
+        self.use_graph = os.environ.get('ACKTR_HIP_GRAPH', '1') != '0'
+        self._graph_key = None
+        self._graphs = None
+        self._seen_key = None
+
+    # one minibatch step = ppo.py:57-84
+    def _fwd_bwd(self, b):
+        ac = self.actor_critic
+        acts = engine.forward(ac, b['obs'], gather_idx=b['idx'])
+        engine.policy_loss(ac, acts, engine.ALGO_PPO, b['actions'], b['loss_acc'], b['inv_batch'],
+                           old_logp=b['old_logp'], old_values=b['old_values'], returns=b['returns'], adv=b['adv'],
+                           gather_idx=b['idx'], clip=self.clip_param, value_coef=self.value_loss_coef,
+                           entropy_coef=self.entropy_coef, use_clipped_value_loss=self.use_clipped_value_loss)
+        engine.backward(ac, acts, ac.flat_grads)
 
     def update(self, rollouts):
         ac = self.actor_critic
@@ -85,30 +116,56 @@ class PPO():
         T, N = rollouts.rewards.size()[0:2]
         rows = T * N
         dev = rollouts.rewards.device
+        mbs = rows // self.num_mini_batch
+        lo, hi = self.dp.bounds(mbs)
+        key = (rollouts.obs.data_ptr(), rollouts.actions.data_ptr(), rollouts.returns.data_ptr(),
+               rollouts.value_preds.data_ptr(), rollouts.action_log_probs.data_ptr(), T, N, mbs, lo, hi,
+               ac.flat_params.data_ptr(), self.clip_param, self.value_loss_coef, self.entropy_coef,
+               self.max_grad_norm, self.use_clipped_value_loss)
         with torch.no_grad():
-            advantages = rollouts.normalized_advantages()                      # ppo.py:35-37
-            loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
-            obs_flat = rollouts.obs[:T].view(rows, *rollouts.obs.size()[2:])
-            actions = rollouts.actions.view(rows, -1)
-            old_values = rollouts.value_preds[:T].view(rows)
-            returns = rollouts.returns[:T].view(rows)
-            old_logp = rollouts.action_log_probs.view(rows)
-            adv = advantages.view(rows)
+            if self._seen_key != key:                       # (re)allocate the persistent per-update buffers
+                self._adv = torch.empty(T, N, 1, dtype=torch.float32, device=dev)
+                self._loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
+                self._idx = torch.zeros(hi - lo, dtype=torch.int64, device=dev)
+                self._graphs, self._graph_key = None, None
+            rollouts.normalized_advantages(out=self._adv)                       # ppo.py:35-37
+            self._loss_acc.zero_()
+            b = dict(obs=rollouts.obs[:T].view(rows, *rollouts.obs.size()[2:]), actions=rollouts.actions.view(rows, -1),
+                     old_values=rollouts.value_preds[:T].view(rows), returns=rollouts.returns[:T].view(rows),
+                     old_logp=rollouts.action_log_probs.view(rows), adv=self._adv.view(rows), idx=self._idx,
+                     loss_acc=self._loss_acc, inv_batch=1.0 / mbs)
             ac.bind_grads()
+            self.optimizer.prepare()
+            graph_ok = self.use_graph and ops.profiler is None and self._seen_key == key
+            if graph_ok and self._graphs is None:           # capture (records only; executes nothing)
+                g1 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    self._fwd_bwd(b)
+                    if not self.dp.active:
+                        self.optimizer.step(self.max_grad_norm, capturing=True)
+                        self.optimizer.step_count -= 1
+                g2 = None
+                if self.dp.active:
+                    g2 = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g2):
+                        self.optimizer.step(self.max_grad_norm, capturing=True)
+                        self.optimizer.step_count -= 1
+                self._graphs, self._graph_key = (g1, g2), key
+            self._seen_key = key
             for e in range(self.ppo_epoch):
                 for indices in rollouts.minibatch_index_batches(self.num_mini_batch):   # ppo.py:48-51
-                    inv_batch = 1.0 / indices.numel()
-                    idx = self.dp.shard(indices).contiguous()
-                    acts = engine.forward(ac, obs_flat, gather_idx=idx)             # ppo.py:57-59
-                    engine.policy_loss(ac, acts, engine.ALGO_PPO, actions, loss_acc, inv_batch,
-                                       old_logp=old_logp, old_values=old_values, returns=returns, adv=adv,
-                                       gather_idx=idx, clip=self.clip_param, value_coef=self.value_loss_coef,
-                                       entropy_coef=self.entropy_coef,
-                                       use_clipped_value_loss=self.use_clipped_value_loss)   # ppo.py:61-81
-                    engine.backward(ac, acts, ac.flat_grads)
-                    self.dp.all_reduce_sum_(ac.flat_grads)
-                    self.optimizer.step(self.max_grad_norm)                        # ppo.py:82-84
-            self.dp.all_reduce_sum_(loss_acc)
+                    self._idx.copy_(indices[lo:hi])
+                    if graph_ok:
+                        self._graphs[0].replay()
+                        if self.dp.active:
+                            self.dp.all_reduce_sum_(ac.flat_grads)
+                            self._graphs[1].replay()
+                        self.optimizer.step_count += 1
+                    else:
+                        self._fwd_bwd(b)
+                        self.dp.all_reduce_sum_(ac.flat_grads)
+                        self.optimizer.step(self.max_grad_norm)                        # ppo.py:82-84
+            self.dp.all_reduce_sum_(self._loss_acc)
             num_updates = self.ppo_epoch * self.num_mini_batch
-            vl, al, en = (loss_acc / num_updates).tolist()                          # the only host sync
+            vl, al, en = (self._loss_acc / num_updates).tolist()                    # the only host sync
         return vl, al, en

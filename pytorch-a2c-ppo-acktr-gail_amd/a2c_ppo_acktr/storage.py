@@ -97,14 +97,15 @@ class RolloutStorage(object):
         _hip.check(rc, 'acktr_compute_returns_f32')
 
     # ------------------------------------------------------------------ advantages (ppo.py:35-37)
-    def normalized_advantages(self):
-        """(R[:-1]-V[:-1] - mean)/(std_unbiased + 1e-5) as a [T,N,1] device tensor."""
+    def normalized_advantages(self, out=None):
+        """(R[:-1]-V[:-1] - mean)/(std_unbiased + 1e-5) as a [T,N,1] device tensor (into `out` if given)."""
         T, N = self.rewards.size(0), self.rewards.size(1)
         L = _hip.lib()
         dev = self.rewards.device
         if self._adv_ws is None or self._adv_ws.device != dev:
             self._adv_ws = torch.empty(L.acktr_adv_normalize_workspace_bytes(), dtype=torch.uint8, device=dev)
-        adv = torch.empty(T, N, 1, dtype=torch.float32, device=dev)
+        adv = out if out is not None else torch.empty(T, N, 1, dtype=torch.float32, device=dev)
+        assert adv.shape == (T, N, 1) and adv.is_contiguous() and adv.device == dev
         rc = L.acktr_adv_normalize_f32(
             _hip.dev_ptr(self.returns, torch.float32, 'returns'),
             _hip.dev_ptr(self.value_preds, torch.float32, 'value_preds'),

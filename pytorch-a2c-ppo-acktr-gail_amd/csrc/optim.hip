@@ -47,14 +47,32 @@ __device__ __forceinline__ float clip_coef_from(const double* partial, int npart
 
 // mode 0: Adam, 1: RMSprop.  use_clip: multiply the gradient by the clip coefficient first (and write it back,
 // as clip_grad_norm_ does in place).
+// hyper_dev (optional): {lr, beta1_or_alpha, beta2, eps} in device memory and step_dev the (already incremented) Adam
+// step counter -- lets a captured hipGraph replay with changing bias corrections / learning rates.
 template <int MODE>
 __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, float* g, float* s1, float* s2, long n,
                                                                   const double* partial, int nparts, int use_clip,
                                                                   float max_norm, float lr_or_step, float beta1,
                                                                   float beta2, float eps, float bc2_sqrt,
-                                                                  float* norm_out) {
+                                                                  float* norm_out, const float* hyper_dev,
+                                                                  const int* step_dev) {
     __shared__ float sm2[2];
     float coef = 1.0f;
+    if (hyper_dev) {
+        const float lr = hyper_dev[0];
+        eps = hyper_dev[3];
+        if (MODE == 0) {
+            beta1 = hyper_dev[1]; beta2 = hyper_dev[2];
+            const int t = *step_dev;
+            const double bc1 = 1.0 - pow((double)beta1, (double)t);     // torch/optim/adam.py:529-535 (host doubles there)
+            const double bc2 = 1.0 - pow((double)beta2, (double)t);
+            lr_or_step = (float)((double)lr / bc1);
+            bc2_sqrt = (float)sqrt(bc2);
+        } else {
+            beta2 = hyper_dev[1];
+            lr_or_step = lr;
+        }
+    }
     if (use_clip) coef = clip_coef_from(partial, nparts, max_norm, sm2, norm_out);
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
         float gi = g[i];
@@ -92,6 +110,8 @@ __global__ __launch_bounds__(OPT_THREADS) void sgd_momentum_kernel(float* p, flo
     }
 }
 
+__global__ void bump_step_kernel(int* step) { *step = *step + 1; }
+
 static int grid_for(long n) {
     int b = cdiv(n, OPT_THREADS * 4);
     if (b > OPT_MAX_PARTIALS) b = OPT_MAX_PARTIALS;
@@ -118,7 +138,28 @@ extern "C" int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, 
     }
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
                        (const double*)workspace, nb, use_clip, max_grad_norm, step_size, beta1, beta2, eps,
-                       bias_correction2_sqrt, total_norm_out);
+                       bias_correction2_sqrt, total_norm_out, (const float*)nullptr, (const int*)nullptr);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                       float max_grad_norm, const float* hyper_dev, int* step_dev, void* workspace,
+                                       void* stream) {
+    ACKTR_ARG(params && grads && exp_avg && exp_avg_sq && workspace && hyper_dev && step_dev, "clip_adam_dev: null pointer");
+    ACKTR_ARG(n > 0, "clip_adam_dev: n must be positive");
+    hipStream_t s = (hipStream_t)stream;
+    const int use_clip = max_grad_norm > 0.f;
+    const int nb = grid_for(n);
+    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
+    ACKTR_LAUNCH_CHECK();
+    if (use_clip) {
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace);
+        ACKTR_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
+                       (const double*)workspace, nb, use_clip, max_grad_norm, 0.f, 0.f, 0.f, 0.f, 1.f, (float*)nullptr,
+                       hyper_dev, (const int*)step_dev);
     ACKTR_LAUNCH_CHECK();
     return 0;
 }
@@ -137,7 +178,7 @@ extern "C" int acktr_clip_rmsprop_f32(float* params, float* grads, float* square
     }
     hipLaunchKernelGGL((clip_update_kernel<1>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, square_avg,
                        (float*)nullptr, n, (const double*)workspace, nb, use_clip, max_grad_norm, lr, 0.f, alpha, eps, 1.f,
-                       total_norm_out);
+                       total_norm_out, (const float*)nullptr, (const int*)nullptr);
     ACKTR_LAUNCH_CHECK();
     return 0;
 }

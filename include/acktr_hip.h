@@ -79,9 +79,11 @@ int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, 
                            int OC, int KH, int KW, int S, void* stream);
 
 /* nn.Linear forward -- model.py:180,185,208-216, distributions.py:69,83.
- * y[B,OUT] = act(x[B,IN] w[OUT,IN]^T + bias);  act: 0 none, 1 relu, 2 tanh. */
+ * y[B,OUT] = act(x[B,IN] w[OUT,IN]^T + bias);  act: 0 none, 1 relu, 2 tanh.  workspace (nullable) enables split-K
+ * for shapes with few output tiles and a long reduction (the 1568->512 layer). */
+long acktr_linear_fwd_workspace_bytes(int B, int IN, int OUT);
 int acktr_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int IN, int OUT, int act,
-                         void* stream);
+                         void* workspace, long workspace_bytes, void* stream);
 /* dx[B,IN] (=|+=) (dy[B,OUT] w[OUT,IN]) * gate;  gate: 0 none, 1 relu' (gate_src > 0), 2 tanh' (1 - gate_src^2),
  * gate_src[B,IN] = the activation that feeds this layer. */
 int acktr_linear_dgrad_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx, int B, int IN,

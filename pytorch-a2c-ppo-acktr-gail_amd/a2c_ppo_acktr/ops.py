@@ -131,9 +131,13 @@ def linear_fwd(x, w, bias, act=None, out=None):
     assert w.shape[1] == IN
     if out is None:
         out = torch.empty(B, OUT, dtype=f32, device=x.device)
+    L = _hip.lib()
+    nb = L.acktr_linear_fwd_workspace_bytes(B, IN, OUT)
+    ws = workspace(x.device, nb) if nb else None
     with _Timed('linear%dx%d_fwd' % (IN, OUT), 2.0 * B * IN * OUT):
-        rc = _hip.lib().acktr_linear_fwd_f32(_p(x, 'x'), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'), B, IN, OUT,
-                                             ACT[act], _hip.cur_stream(x.device))
+        rc = L.acktr_linear_fwd_f32(_p(x, 'x'), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'), B, IN, OUT, ACT[act],
+                                    _p(ws, 'workspace', torch.uint8), ws.numel() if ws is not None else 0,
+                                    _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_linear_fwd_f32')
     return out
 

@@ -53,7 +53,7 @@ static int conv_wgrad_t(const float* x, const int64_t* idx, const float* dy, flo
     const int Kc = C * KH * KW, R = B * SP;
     const long bias_floats = db ? (long)64 * OC : 0;
     const long tiles = (long)cdiv(OC, BM) * cdiv(Kc, 128);
-    long max_by_ws = (ws_floats - bias_floats) / ((long)OC * Kc);
+    long max_by_ws = (ws_floats - bias_floats) / ((long)OC * Kc) - SLAB_GROUP_EXTRA;
     int ns = pick_slices(tiles, R, max_by_ws < 1 ? 1 : max_by_ws);
     if (ns > 1 && max_by_ws < ns) ns = 1;
     ConvOutKC<SP> gop{dy, OC, R};
@@ -73,11 +73,11 @@ static int conv_wgrad_t(const float* x, const int64_t* idx, const float* dy, flo
         if (rc) return rc;
     }
     if (db) {
-        if (ws_floats < bias_floats + (ns > 1 ? (long)ns * OC * Kc : 0)) {
+        if (ws_floats < bias_floats + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OC * Kc : 0)) {
             set_error("conv2d_wgrad: workspace too small for bias partials");
             return -1;
         }
-        float* part = ws + (ns > 1 ? (long)ns * OC * Kc : 0);
+        float* part = ws + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OC * Kc : 0);
         int nsl = B < 64 ? B : 64;
         const int ips = cdiv(B, nsl);
         nsl = cdiv(B, ips);
@@ -142,7 +142,7 @@ extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, i
     const long Kc = (long)C * KH * KW;
     const int BM = OC <= 32 ? 32 : 64;
     const int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OW, 1024);
-    return ((long)ns * OC * Kc + (long)64 * OC) * (long)sizeof(float);
+    return ((long)(ns + SLAB_GROUP_EXTRA) * OC * Kc + (long)64 * OC) * (long)sizeof(float);
 }
 
 extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw,

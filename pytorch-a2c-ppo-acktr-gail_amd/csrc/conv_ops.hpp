@@ -121,24 +121,43 @@ struct DgradDy {   // N-operand: rows = input positions of one phase, k = (oc, a
     using G = DgradGeom<KH, KW, S, OH, OW>;
     static constexpr bool INNER_IS_K = true;
     const float* dy; int OC; int NP; int Kred;
-    struct Outer { const float* p; int jy, jx, ok; };
+    // per position: pointer to dY[b, 0, jy, jx] and a TAPS-bit mask of the taps (a, a') whose source pixel
+    // (jy-a, jx-a') lies inside the output map -- all bounds tests are done once per row, not per element
+    struct Outer { const float* p; unsigned mask; };
     __device__ __forceinline__ Outer prep(int pos) const {
-        Outer o; o.ok = pos < NP; const int pp = o.ok ? pos : 0;
+        Outer o; o.mask = 0u;
+        const bool ok = pos < NP; const int pp = ok ? pos : 0;
         const int b = pp / G::JP, j = pp % G::JP;
-        o.jy = j / G::JW; o.jx = j % G::JW;
-        o.p = dy + (long)b * OC * G::SP;
+        const int jy = j / G::JW, jx = j % G::JW;
+        o.p = dy + (long)b * OC * G::SP + jy * OW + jx;
+        if (ok) {
+#pragma unroll
+            for (int t = 0; t < G::TAPS; ++t) {
+                const int oy = jy - t / G::TB, ox = jx - t % G::TB;
+                if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) o.mask |= (1u << t);
+            }
+        }
         return o;
     }
     __device__ __forceinline__ f32x4 ld4(const Outer& o, int k0) const {
         f32x4 v = zero4();
-        if (!o.ok) return v;
+        if (o.mask == 0u || k0 >= Kred) return v;
+        if constexpr (G::TAPS % 4 == 0) {          // 4 consecutive k share one oc (Kred % 4 == 0)
+            const int oc = k0 / G::TAPS, t0 = k0 % G::TAPS;
+            const float* q = o.p + (long)oc * G::SP;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + j;
-            if (k < Kred) {
-                const int oc = k / G::TAPS, tap = k % G::TAPS;
-                const int oy = o.jy - tap / G::TB, ox = o.jx - tap % G::TB;
-                if (oy >= 0 && oy < OH && ox >= 0 && ox < OW) v[j] = o.p[(long)oc * G::SP + oy * OW + ox];
+            for (int j = 0; j < 4; ++j) {
+                const int t = t0 + j;              // t0 is a multiple of 4: compile-time tap geometry per j
+                if ((o.mask >> t) & 1u) v[j] = q[-((t / G::TB) * OW + (t % G::TB))];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = k0 + j;
+                if (k < Kred) {
+                    const int oc = k / G::TAPS, t = k % G::TAPS;
+                    if ((o.mask >> t) & 1u) v[j] = o.p[(long)oc * G::SP - ((t / G::TB) * OW + (t % G::TB))];
+                }
             }
         }
         return v;

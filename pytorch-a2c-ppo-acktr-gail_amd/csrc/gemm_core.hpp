@@ -300,8 +300,13 @@ static inline RowMajorEpi row_major_epi(float* c, int M, int N, long ldc) {
     e.div_m = nullptr; e.div_n = nullptr; e.div_add = 0.f; return e;
 }
 
-// Fixed-order slab reduction: dst[i] (=|+=) scale * sum_s slabs[s*stride + i]
+// Fixed-order slab reduction: dst[i] (=|+=) scale * sum_s slabs[s*stride + i].  With >= 16 slabs it runs in two
+// passes and keeps up to SLAB_GROUP_EXTRA group partials right behind the slabs: size workspaces accordingly.
+constexpr int SLAB_GROUP_EXTRA = 32;
 int launch_slab_reduce(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,
                        hipStream_t stream);
+// Same with a fused epilogue on the final pass: (+ bias[i % ncols]) -> act (0 none, 1 relu, 2 tanh).
+int launch_slab_reduce_ex(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,
+                          const float* bias, int ncols, int act, float* group_ws, hipStream_t stream);
 
 }  // namespace acktr

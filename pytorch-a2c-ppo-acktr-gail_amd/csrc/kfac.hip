@@ -26,7 +26,7 @@ static int cov_a_conv_t(const float* x, const int64_t* idx, int B, int C, float 
     const int Kc = C * KH * KW, R = B * Patch::SP;
     Patch pop{x, idx, C, (long)C * H * W, R, Kc};
     const long tiles = (long)cdiv(Kc, 128) * cdiv(Kc, 128);
-    long max_by_ws = ws_floats / ((long)Kc * Kc);
+    long max_by_ws = ws_floats / ((long)Kc * Kc) - SLAB_GROUP_EXTRA;
     int ns = pick_slices(tiles, R, max_by_ws < 1 ? 1 : max_by_ws);
     if (ns > 1 && max_by_ws < ns) ns = 1;
     if (ns == 1) {
@@ -46,7 +46,7 @@ static int cov_g_conv_t(const float* dy, int B, int OC, float alpha, float* out,
                         hipStream_t s) {
     const int R = B * SP;
     ConvOutKC<SP> gop{dy, OC, R};
-    long max_by_ws = ws_floats / ((long)OC * OC);
+    long max_by_ws = ws_floats / ((long)OC * OC) - SLAB_GROUP_EXTRA;
     int ns = pick_slices(1, R, max_by_ws < 1 ? 1 : max_by_ws);
     if (ns > 512) ns = 512;
     if (ns > 1 && max_by_ws < ns) ns = 1;
@@ -250,7 +250,7 @@ extern "C" long acktr_kfac_cov_workspace_bytes(int D, long R) {
     const long tiles = (long)cdiv(D, 128) * cdiv(D, 128);
     int ns = pick_slices(tiles, R, 1024);
     if (ns > 512) ns = 512;
-    return (long)ns * D * D * (long)sizeof(float);
+    return (long)(ns + SLAB_GROUP_EXTRA) * D * D * (long)sizeof(float);
 }
 
 extern "C" int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_idx, int B, int C, int H, int W,
@@ -291,7 +291,7 @@ extern "C" int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, 
     float* ws = (float*)workspace;
     const long wf = workspace ? workspace_bytes / (long)sizeof(float) : 0;
     const long tiles = (long)cdiv(D, 128) * cdiv(D, 128);
-    long max_by_ws = wf / ((long)D * D);
+    long max_by_ws = wf / ((long)D * D) - SLAB_GROUP_EXTRA;
     int ns = pick_slices(tiles, B, max_by_ws < 1 ? 1 : max_by_ws);
     if (ns > 1 && max_by_ws < ns) ns = 1;
     // out[i, j] = alpha * sum_b a[b, i] a[b, j]  : both operands row contiguous (k = b)

@@ -6,6 +6,71 @@
 
 namespace acktr {
 
+// Fixed-order slab reduction in float4 units.  One pass when there are few slabs; otherwise two passes:
+// pass 1 sums groups of slabs in parallel (grid.y = groups) into group partials, pass 2 sums the groups.
+// Both orders are fixed, so split-K results are run-to-run deterministic.
+// Epilogue (final pass only): v = scale*sum (+ bias[i % ncols]) -> act -> (+= dst).
+__global__ __launch_bounds__(256) void slab_reduce4_kernel(float* dst, const float* slabs, int first, int count,
+                                                           long n4, long stride, float scale, int accumulate,
+                                                           const float* bias, int ncols, int act, int group_stride,
+                                                           long dst_group_stride) {
+    const int g = blockIdx.y;
+    const int s0 = first + g * group_stride;
+    int s1 = s0 + group_stride;
+    if (s1 > first + count) s1 = first + count;
+    float* out = dst + (long)g * dst_group_stride;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        f32x4 acc = zero4();
+        int k = s0;
+        for (; k + 4 <= s1; k += 4) {          // 4 independent loads in flight, summed in slab order
+            const f32x4 a = *reinterpret_cast<const f32x4*>(slabs + (long)k * stride + 4 * i);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(slabs + (long)(k + 1) * stride + 4 * i);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(slabs + (long)(k + 2) * stride + 4 * i);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(slabs + (long)(k + 3) * stride + 4 * i);
+            acc = acc + a; acc = acc + b; acc = acc + c; acc = acc + d;
+        }
+        for (; k < s1; ++k) acc = acc + *reinterpret_cast<const f32x4*>(slabs + (long)k * stride + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v = acc[j] * scale;
+            if (bias) v += bias[(4 * i + j) % ncols];
+            if (act == 1) v = v > 0.f ? v : 0.f;
+            else if (act == 2) v = tanhf(v);
+            if (accumulate) v += out[4 * i + j];
+            out[4 * i + j] = v;
+        }
+    }
+}
+
+int launch_slab_reduce_ex(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,
+                          const float* bias, int ncols, int act, float* group_ws, hipStream_t stream) {
+    if (n <= 0) return 0;
+    if ((n & 3) || (stride & 3) || (((uintptr_t)dst | (uintptr_t)slabs) & 15)) {
+        set_error("slab_reduce: n, stride must be multiples of 4 and pointers 16-byte aligned");
+        return -1;
+    }
+    const long n4 = n / 4;
+    int bx = cdiv(n4, 256);
+    if (bx > 1024) bx = 1024;
+    const int groups = (group_ws && nslabs >= 16) ? (nslabs >= 128 ? 32 : 8) : 1;
+    if (groups == 1) {
+        hipLaunchKernelGGL(slab_reduce4_kernel, dim3(bx, 1), dim3(256), 0, stream, dst, slabs, 0, nslabs, n4, stride, scale,
+                           accumulate, bias, ncols, act, nslabs, 0L);
+        ACKTR_LAUNCH_CHECK();
+        return 0;
+    }
+    const int per = cdiv(nslabs, groups);
+    const int ng = cdiv(nslabs, per);
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(bx, ng), dim3(256), 0, stream, group_ws, slabs, 0, nslabs, n4, stride, 1.0f,
+                       0, (const float*)nullptr, 1, 0, per, n);
+    ACKTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(slab_reduce4_kernel, dim3(bx, 1), dim3(256), 0, stream, dst, (const float*)group_ws, 0, ng, n4, n, scale,
+                       accumulate, bias, ncols, act, ng, 0L);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+// scalar fallback for tiny / unaligned reductions (bias partials etc.)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(float* dst, const float* slabs, int nslabs, long n,
                                                           long stride, float scale, int accumulate) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -20,6 +85,12 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(float* dst, const floa
 int launch_slab_reduce(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,
                        hipStream_t stream) {
     if (n <= 0) return 0;
+    if (!(n & 3) && !(stride & 3) && !(((uintptr_t)dst | (uintptr_t)slabs) & 15)) {
+        // group partials live right behind the slabs (callers size workspaces with SLAB_GROUP_EXTRA slabs of slack)
+        float* gws = const_cast<float*>(slabs) + (long)nslabs * stride;
+        return launch_slab_reduce_ex(dst, slabs, nslabs, n, stride, scale, accumulate, nullptr, 1, 0,
+                                     nslabs >= 16 ? gws : nullptr, stream);
+    }
     int blocks = cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(slab_reduce_kernel, dim3(blocks), dim3(256), 0, stream, dst, slabs, nslabs, n, stride, scale,
@@ -41,12 +112,26 @@ __global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* a, in
     partial[(long)blockIdx.y * cols + c] = s;
 }
 
+// Tile choice: 128x128 when it alone fills the chip, else 64x128 (twice the workgroups), skinny shapes get
+// 128x32 / 32x128.  256 CUs want a few hundred workgroups; split-K supplies the rest (see pick_slices).
+static int tile_rows_for(int M, int N) {
+    if (N <= 64) return 128;
+    if (M <= 32) return 32;
+    if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) return 128;
+    return 64;
+}
 template <class MOp, class NOp, class Epi>
 static int gemm_dispatch(const MOp& mop, const NOp& nop, const Epi& epi, int M, int N, int K, int nslices,
                          hipStream_t s) {
     if (N <= 64) return launch_gemm<128, 32, 4, 1>(mop, nop, epi, M, N, K, nslices, s);
-    if (M <= 64) return launch_gemm<32, 128, 1, 4>(mop, nop, epi, M, N, K, nslices, s);
+    const int bm = tile_rows_for(M, N);
+    if (bm == 32) return launch_gemm<32, 128, 1, 4>(mop, nop, epi, M, N, K, nslices, s);
+    if (bm == 64) return launch_gemm<64, 128, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
     return launch_gemm<128, 128, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
+}
+long gemm_tiles(int M, int N) {
+    if (N <= 64) return (long)cdiv(M, 128) * cdiv(N, 32);
+    return (long)cdiv(M, tile_rows_for(M, N)) * cdiv(N, 128);
 }
 
 // Generic C[M,N] (row major, ldc) = A(m,k) * B(n,k) with explicit element strides per operand:
@@ -88,15 +173,42 @@ int pick_slices(long tiles, long K, long max_by_ws) {
 
 using namespace acktr;
 
+static int fwd_slices(int B, int IN, int OUT, long ws_floats) {
+    if (((long)B * OUT) % 4) return 1;
+    long max_by_ws = ws_floats / ((long)B * OUT) - SLAB_GROUP_EXTRA;
+    long want = 512 / gemm_tiles(B, OUT);
+    long by_k = IN / (8 * GK);                 // at least 8 K tiles per slice
+    long n = want < by_k ? want : by_k;
+    if (n > max_by_ws) n = max_by_ws;
+    if (n > 16) n = 16;
+    return n < 2 ? 1 : (int)n;
+}
+
+extern "C" long acktr_linear_fwd_workspace_bytes(int B, int IN, int OUT) {
+    const int ns = fwd_slices(B, IN, OUT, 1L << 40);
+    return ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * B * OUT * (long)sizeof(float) : 0;
+}
+
 extern "C" int acktr_linear_fwd_f32(const float* x, const float* w, const float* bias, float* y, int B, int IN,
-                                    int OUT, int act, void* stream) {
+                                    int OUT, int act, void* workspace, long workspace_bytes, void* stream) {
     ACKTR_ARG(x && w && y, "linear_fwd: null pointer");
     ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_fwd: bad sizes B=%d IN=%d OUT=%d", B, IN, OUT);
     ACKTR_ARG(act >= 0 && act <= 2, "linear_fwd: act must be 0 (none), 1 (relu) or 2 (tanh)");
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const int ns = (ws && (((uintptr_t)ws | (uintptr_t)y) & 15) == 0)
+                       ? fwd_slices(B, IN, OUT, workspace_bytes / (long)sizeof(float)) : 1;
+    if (ns > 1) {   // few output tiles, long K: split K into slabs, bias + activation fused into the reduction
+        RowMajorEpi e = row_major_epi(ws, B, OUT, OUT);
+        e.slab_stride = (long)B * OUT;
+        int rc = gemm_rowmajor(x, IN, 1, w, IN, 1, e, B, OUT, IN, ns, s);
+        if (rc) return rc;
+        return launch_slab_reduce_ex(y, ws, ns, (long)B * OUT, (long)B * OUT, 1.f, 0, bias, OUT, act, nullptr, s);
+    }
     RowMajorEpi e = row_major_epi(y, B, OUT, OUT);
     e.bias_n = bias;
     e.act = act;
-    return gemm_rowmajor(x, IN, 1, w, IN, 1, e, B, OUT, IN, 1, (hipStream_t)stream);
+    return gemm_rowmajor(x, IN, 1, w, IN, 1, e, B, OUT, IN, 1, s);
 }
 
 extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx,
@@ -111,9 +223,9 @@ extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const flo
 }
 
 extern "C" long acktr_linear_wgrad_workspace_bytes(int B, int IN, int OUT) {
-    const long tiles = (long)cdiv(OUT, 128) * cdiv(IN, 128);
+    const long tiles = gemm_tiles(OUT, IN);
     const int ns = pick_slices(tiles, B, 1024);
-    return ((long)ns * OUT * IN + (long)64 * OUT) * (long)sizeof(float);
+    return ((long)(ns + SLAB_GROUP_EXTRA) * OUT * IN + (long)64 * OUT) * (long)sizeof(float);
 }
 
 extern "C" int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT,
@@ -124,11 +236,10 @@ extern "C" int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw
     float* ws = (float*)workspace;
     const long ws_floats = workspace ? workspace_bytes / (long)sizeof(float) : 0;
     const long bias_floats = db ? (long)64 * OUT : 0;
-    const long tiles = (long)cdiv(OUT, 128) * cdiv(IN, 128);
-    long max_by_ws = (ws_floats - bias_floats) / ((long)OUT * IN);
-    if (max_by_ws < 1) max_by_ws = 1;
-    int ns = pick_slices(tiles, B, max_by_ws);
-    if (ns > 1 && (ws_floats - bias_floats) < (long)ns * OUT * IN) ns = 1;
+    const long tiles = gemm_tiles(OUT, IN);
+    long max_by_ws = (ws_floats - bias_floats) / ((long)OUT * IN) - SLAB_GROUP_EXTRA;
+    int ns = pick_slices(tiles, B, max_by_ws < 1 ? 1 : max_by_ws);
+    if (ns > 1 && max_by_ws < ns) ns = 1;
     // dW[o, i] = sum_b dY[b, o] * X[b, i] : A(m=o, k=b) = dy[b*OUT + o], B(n=i, k=b) = x[b*IN + i]
     int rc;
     if (ns == 1) {
@@ -144,9 +255,9 @@ extern "C" int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw
         if (rc) return rc;
     }
     if (db) {
-        ACKTR_ARG(ws_floats >= bias_floats + (ns > 1 ? (long)ns * OUT * IN : 0),
+        ACKTR_ARG(ws_floats >= bias_floats + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OUT * IN : 0),
                   "linear_wgrad: workspace too small for the bias partials (%ld floats)", ws_floats);
-        float* part = ws + (ns > 1 ? (long)ns * OUT * IN : 0);
+        float* part = ws + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OUT * IN : 0);
         int nsl = cdiv(B, 64);
         if (nsl > 64) nsl = 64;
         const int rps = cdiv(B, nsl);

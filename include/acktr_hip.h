@@ -74,9 +74,11 @@ int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const floa
                            long workspace_bytes, void* stream);
 
 /* autograd backward w.r.t. the input: dx[B,C,H,W] = conv_transpose(dy, w) (* (x_act > 0) when x_act is
- * given: the ReLU backward of the layer that produced x, model.py:177-179). */
+ * given: the ReLU backward of the layer that produced x, model.py:177-179).  `workspace` (16-byte aligned,
+ * ..._workspace_bytes) receives the weights re-packed per stride phase for 16-byte operand streaming. */
+long acktr_conv2d_dgrad_workspace_bytes(int C, int OC, int KH, int KW, int S);
 int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
-                           int OC, int KH, int KW, int S, void* stream);
+                           int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, void* stream);
 
 /* nn.Linear forward -- model.py:180,185,208-216, distributions.py:69,83.
  * y[B,OUT] = act(x[B,IN] w[OUT,IN]^T + bias);  act: 0 none, 1 relu, 2 tanh.  workspace (nullable) enables split-K

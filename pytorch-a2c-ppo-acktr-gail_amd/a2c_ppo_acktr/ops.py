@@ -115,9 +115,12 @@ def conv2d_dgrad(dy, w, x_act, stride, out=None):
     if out is None:
         out = torch.empty(B, C, H, W, dtype=f32, device=dy.device)
     assert out.shape == (B, C, H, W) and (x_act is None or x_act.shape == out.shape)
+    L = _hip.lib()
+    ws = workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(C, OC, KH, KW, stride), tag='dgrad')
     with _Timed('conv%ds%d_dgrad' % (KH, stride), 2.0 * dy.numel() * C * KH * KW):
-        rc = _hip.lib().acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
-                                               B, C, H, W, OC, KH, KW, stride, _hip.cur_stream(dy.device))
+        rc = L.acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
+                                      B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),
+                                      _hip.cur_stream(dy.device))
     _hip.check(rc, 'acktr_conv2d_dgrad_f32')
     return out
 

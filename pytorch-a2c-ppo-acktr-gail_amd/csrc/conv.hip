@@ -45,19 +45,27 @@ static int conv_fwd_t(const float* x, const int64_t* idx, const float* w, const 
     return launch_gemm<BM, 128, WM, WN>(wop, pop, epi, OC, R, Kc, 1, s);
 }
 
-template <int KH, int KW, int S, int H, int W, int BM, int WM, int WN>
-static int conv_wgrad_t(const float* x, const int64_t* idx, const float* dy, float* dw, float* db, int B, int C,
-                        int OC, float scale, float* ws, long ws_floats, hipStream_t s) {
-    using Patch = Im2col<KH, KW, S, H, W, false>;
-    constexpr int SP = Patch::SP;
-    const int Kc = C * KH * KW, R = B * SP;
+// stride-1 layers: positions are the contiguous axis of the im2col operand (one dwordx4 per 4 positions)
+template <int KH, int KW, int H, int W, int OWP, int BM, int WM, int WN>
+static int conv_fwd_pos_t(const float* x, const float* w, const float* bias, float* y, int B, int C, int OC,
+                          float scale, int relu, hipStream_t s) {
+    using Patch = Im2colPos<KH, KW, H, W, OWP, false>;
+    const int Kc = C * KH * KW, RP = B * Patch::PP;
+    DenseKC wop{w, OC, Kc, (long)Kc, vec_ok(w, Kc)};
+    Patch pop{x, x + (long)B * C * H * W, C, RP, Kc};
+    ConvFwdEpiPos<Patch::OH, Patch::OW, OWP> epi{y, bias, OC, RP, scale, relu};
+    return launch_gemm<BM, 128, WM, WN>(wop, pop, epi, OC, RP, Kc, 1, s);
+}
+
+// dW[oc, kk] = scale * sum_r G(oc, r) * P(kk, r) with split-K over the position axis (R positions, padded or not)
+template <int BM, int WM, int WN, class GOp, class POp>
+static int conv_wgrad_core(const GOp& gop, const POp& pop, const float* dy, float* dw, float* db, int B, int OC, int Kc,
+                           int R, int SP, float scale, float* ws, long ws_floats, hipStream_t s) {
     const long bias_floats = db ? (long)64 * OC : 0;
     const long tiles = (long)cdiv(OC, BM) * cdiv(Kc, 128);
     long max_by_ws = (ws_floats - bias_floats) / ((long)OC * Kc) - SLAB_GROUP_EXTRA;
     int ns = pick_slices(tiles, R, max_by_ws < 1 ? 1 : max_by_ws);
     if (ns > 1 && max_by_ws < ns) ns = 1;
-    ConvOutKC<SP> gop{dy, OC, R};
-    Patch pop{x, idx, C, (long)C * H * W, R, Kc};
     int rc;
     if (ns == 1) {
         RowMajorEpi e = row_major_epi(dw, OC, Kc, Kc);
@@ -89,20 +97,78 @@ static int conv_wgrad_t(const float* x, const int64_t* idx, const float* dy, flo
     return 0;
 }
 
+template <int KH, int KW, int S, int H, int W, int BM, int WM, int WN>
+static int conv_wgrad_t(const float* x, const int64_t* idx, const float* dy, float* dw, float* db, int B, int C,
+                        int OC, float scale, float* ws, long ws_floats, hipStream_t s) {
+    using Patch = Im2col<KH, KW, S, H, W, false>;
+    constexpr int SP = Patch::SP;
+    const int Kc = C * KH * KW, R = B * SP;
+    ConvOutKC<SP> gop{dy, OC, R};
+    Patch pop{x, idx, C, (long)C * H * W, R, Kc};
+    return conv_wgrad_core<BM, WM, WN>(gop, pop, dy, dw, db, B, OC, Kc, R, SP, scale, ws, ws_floats, s);
+}
+
+// stride-1 layers without a gather: both operands stream 4 padded positions per 16-byte load
+template <int KH, int KW, int H, int W, int OWP, int BM, int WM, int WN>
+static int conv_wgrad_pos_t(const float* x, const float* dy, float* dw, float* db, int B, int C, int OC, float scale,
+                            float* ws, long ws_floats, hipStream_t s) {
+    using Patch = Im2colPos<KH, KW, H, W, OWP, true>;
+    const int Kc = C * KH * KW, RP = B * Patch::PP;
+    ConvOutPos<Patch::OH, Patch::OW, OWP> gop{dy, dy + (long)B * OC * Patch::OH * Patch::OW, OC, RP};
+    Patch pop{x, x + (long)B * C * H * W, C, RP, Kc};
+    return conv_wgrad_core<BM, WM, WN>(gop, pop, dy, dw, db, B, OC, Kc, RP, Patch::OH * Patch::OW, scale, ws, ws_floats,
+                                       s);
+}
+
+// dgrad weights re-packed once per call into dense per-phase matrices Wp[phase][c][k], k = (oc, a, a'), rows padded
+// to a multiple of 4: the GEMM's M operand then streams 16-byte rows instead of gathering 4-byte taps that sit
+// KH*KW*C floats apart (one cache line per lane).
+template <int KH, int KW, int S>
+__global__ __launch_bounds__(256) void dgrad_pack_w_kernel(const float* w, float* wp, int C, int OC, int Kredp) {
+    constexpr int TB = (KW + S - 1) / S, TA = (KH + S - 1) / S, TAPS = TA * TB;
+    const long n = (long)S * S * C * Kredp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kredp);
+        const int c = (int)((i / Kredp) % C);
+        const int ph = (int)(i / ((long)Kredp * C));
+        const int oc = k / TAPS, t = k % TAPS;
+        const int ky = ph / S + S * (t / TB), kx = ph % S + S * (t % TB);
+        float v = 0.f;
+        if (oc < OC && ky < KH && kx < KW) v = w[((long)oc * C + c) * (KH * KW) + ky * KW + kx];
+        wp[i] = v;
+    }
+}
+
+struct DgradWPacked {   // M-operand: rows = input channel c of phase blockIdx.z, k contiguous
+    static constexpr bool INNER_IS_K = true;
+    const float* wp; int C; int Kredp;
+    struct Outer { const float* rp; int ok; };
+    __device__ __forceinline__ Outer prep(int c) const {
+        Outer o; o.ok = c < C; o.rp = wp + ((long)blockIdx.z * C + (o.ok ? c : 0)) * Kredp; return o;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, int k0) const {
+        if (!o.ok || k0 >= Kredp) return zero4();
+        return *reinterpret_cast<const f32x4*>(o.rp + k0);
+    }
+};
+
 template <int KH, int KW, int S, int OH, int OW, int BM, int WM, int WN>
 static int conv_dgrad_t(const float* dy, const float* w, const float* xact, float* dx, int B, int C, int OC,
-                        hipStream_t s) {
+                        float* wp, hipStream_t s) {
     using G = DgradGeom<KH, KW, S, OH, OW>;
-    const int Kred = OC * G::TAPS, NP = B * G::JP;
-    for (int py = 0; py < S; ++py)
-        for (int px = 0; px < S; ++px) {
-            DgradW<KH, KW, S, OH, OW> wop{w, C, Kred, py, px};
-            DgradDy<KH, KW, S, OH, OW> gop{dy, OC, NP, Kred};
-            DgradEpi<KH, KW, S, OH, OW> epi{dx, xact, C, NP, py, px};
-            int rc = launch_gemm<BM, 128, WM, WN>(wop, gop, epi, C, NP, Kred, 1, s);
-            if (rc) return rc;
-        }
-    return 0;
+    const int Kred = OC * G::TAPS, Kredp = (Kred + 3) / 4 * 4;
+    const long npack = (long)S * S * C * Kredp;
+    hipLaunchKernelGGL((dgrad_pack_w_kernel<KH, KW, S>), dim3((unsigned)((npack + 255) / 256)), dim3(256), 0, s, w, wp,
+                       C, OC, Kredp);
+    ACKTR_LAUNCH_CHECK();
+    DgradWPacked wop{wp, C, Kredp};
+    // all S*S stride phases in ONE launch: blockIdx.z selects the phase (the K range is never split here)
+    // (a position-contiguous 16-byte dY loader was measured slower here: the padded phase rows cost more MFMA
+    //  work than the wider loads save)
+    const int NP = B * G::JP;
+    DgradDy<KH, KW, S, OH, OW> gop{dy, OC, NP, Kred};
+    DgradEpi<KH, KW, S, OH, OW> epi{dx, xact, C, NP};
+    return launch_gemm_z<BM, 128, WM, WN>(wop, gop, epi, C, NP, Kred, S * S, s);
 }
 }  // namespace acktr
 
@@ -132,8 +198,12 @@ extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, c
         if (OC <= 32) return conv_fwd_t<4, 4, 2, 20, 20, 32, 1, 4>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
         return conv_fwd_t<4, 4, 2, 20, 20, 64, 2, 2>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
     }
-    if (OC <= 32) return conv_fwd_t<3, 3, 1, 9, 9, 32, 1, 4>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
-    return conv_fwd_t<3, 3, 1, 9, 9, 64, 2, 2>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
+    if (gather_idx) {
+        if (OC <= 32) return conv_fwd_t<3, 3, 1, 9, 9, 32, 1, 4>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
+        return conv_fwd_t<3, 3, 1, 9, 9, 64, 2, 2>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
+    }
+    if (OC <= 32) return conv_fwd_pos_t<3, 3, 9, 9, 8, 32, 1, 4>(x, w, bias, y, B, C, OC, in_scale, relu, s);
+    return conv_fwd_pos_t<3, 3, 9, 9, 8, 64, 2, 2>(x, w, bias, y, B, C, OC, in_scale, relu, s);
 }
 
 extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, int OC, int KH, int KW, int S) {
@@ -141,7 +211,8 @@ extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, i
     const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1;
     const long Kc = (long)C * KH * KW;
     const int BM = OC <= 32 ? 32 : 64;
-    const int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OW, 1024);
+    const int OWP = (OW + 3) / 4 * 4;      // the stride-1 path reduces over padded positions
+    const int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OWP, 1024);
     return ((long)(ns + SLAB_GROUP_EXTRA) * OC * Kc + (long)64 * OC) * (long)sizeof(float);
 }
 
@@ -160,19 +231,37 @@ extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx,
               : conv_wgrad_t<KH_, KW_, S_, H_, W_, 64, 2, 2>(x, gather_idx, dy, dw, db, B, C, OC, in_scale, ws, wf, s))
     if (geom == GEOM_8S4) return WG(8, 8, 4, 84, 84);
     if (geom == GEOM_4S2) return WG(4, 4, 2, 20, 20);
-    return WG(3, 3, 1, 9, 9);
+    if (gather_idx) return WG(3, 3, 1, 9, 9);
 #undef WG
+    if (OC <= 32) return conv_wgrad_pos_t<3, 3, 9, 9, 8, 32, 1, 4>(x, dy, dw, db, B, C, OC, in_scale, ws, wf, s);
+    return conv_wgrad_pos_t<3, 3, 9, 9, 8, 64, 2, 2>(x, dy, dw, db, B, C, OC, in_scale, ws, wf, s);
+}
+
+static long dgrad_ws_floats(int C, int OC, int KH, int KW, int S) {
+    const int taps = ((KH + S - 1) / S) * ((KW + S - 1) / S);
+    const long kredp = ((long)OC * taps + 3) / 4 * 4;
+    return (long)S * S * C * kredp;
+}
+
+extern "C" long acktr_conv2d_dgrad_workspace_bytes(int C, int OC, int KH, int KW, int S) {
+    if (C <= 0 || OC <= 0 || KH <= 0 || KW <= 0 || S <= 0) return 0;
+    return dgrad_ws_floats(C, OC, KH, KW, S) * (long)sizeof(float);
 }
 
 extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C,
-                                      int H, int W, int OC, int KH, int KW, int S, void* stream) {
+                                      int H, int W, int OC, int KH, int KW, int S, void* workspace,
+                                      long workspace_bytes, void* stream) {
     ACKTR_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     const bool gather_ok = false;
     CONV_COMMON_CHECKS("conv2d_dgrad");
+    ACKTR_ARG(workspace && workspace_bytes >= dgrad_ws_floats(C, OC, KH, KW, S) * (long)sizeof(float),
+              "conv2d_dgrad: workspace too small (%ld bytes given)", workspace_bytes);
+    ACKTR_ARG(((uintptr_t)workspace & 15) == 0, "conv2d_dgrad: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-#define DG(KH_, KW_, S_, OH_, OW_)                                                              \
-    (C <= 32 ? conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 32, 1, 4>(dy, w, x_act, dx, B, C, OC, s)    \
-             : conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 64, 2, 2>(dy, w, x_act, dx, B, C, OC, s))
+    float* wp = (float*)workspace;
+#define DG(KH_, KW_, S_, OH_, OW_)                                                                 \
+    (C <= 32 ? conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 32, 1, 4>(dy, w, x_act, dx, B, C, OC, wp, s)   \
+             : conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 64, 2, 2>(dy, w, x_act, dx, B, C, OC, wp, s))
     if (geom == GEOM_8S4) return DG(8, 8, 4, 20, 20);
     if (geom == GEOM_4S2) return DG(4, 4, 2, 9, 9);
     return DG(3, 3, 1, 7, 7);

@@ -5,6 +5,9 @@
 
 namespace acktr {
 
+// 16-byte vector load from a 4-byte-aligned address: ONE global_load_dwordx4 on gfx950
+typedef f32x4 f32x4_u __attribute__((aligned(4)));
+
 // ------------------------------------------------------------------------------------------
 // im2col patches of X [B(,gathered), C, H, W]:  element (r = (b,oy,ox), kk = (c,ky,kx))
 //   INNER_K = true : forward N-operand (rows = positions, k = patch index)
@@ -35,14 +38,8 @@ struct Im2col {
             const float* q = o.p + c * HW + (rem / KW) * W + (rem % KW);
             if constexpr (S % 4 == 0 && W % 4 == 0) {
                 return *reinterpret_cast<const f32x4*>(q);
-            } else if constexpr (S % 2 == 0 && W % 2 == 0) {
-                const float2 a = *reinterpret_cast<const float2*>(q);
-                const float2 b = *reinterpret_cast<const float2*>(q + 2);
-                v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
-                return v;
-            } else {
-                v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-                return v;
+            } else {                          // the 4 taps lie inside the image row: one unaligned 16-byte load
+                return *reinterpret_cast<const f32x4_u*>(q);
             }
         } else {
 #pragma unroll
@@ -165,35 +162,12 @@ struct DgradDy {   // N-operand: rows = input positions of one phase, k = (oc, a
 };
 
 template <int KH, int KW, int S, int OH, int OW>
-struct DgradW {    // M-operand: rows = input channel c, k = (oc, a, a') -> W[oc, c, py+S*a, px+S*a']
-    using G = DgradGeom<KH, KW, S, OH, OW>;
-    static constexpr bool INNER_IS_K = true;
-    const float* w; int C; int Kred; int py, px;
-    struct Outer { const float* p; int ok; };
-    __device__ __forceinline__ Outer prep(int c) const {
-        Outer o; o.ok = c < C; o.p = w + (long)(o.ok ? c : 0) * (KH * KW); return o;
-    }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int k0) const {
-        f32x4 v = zero4();
-        if (!o.ok) return v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int k = k0 + j;
-            if (k < Kred) {
-                const int oc = k / G::TAPS, tap = k % G::TAPS;
-                v[j] = o.p[(long)oc * C * (KH * KW) + (py + S * (tap / G::TB)) * KW + (px + S * (tap % G::TB))];
-            }
-        }
-        return v;
-    }
-};
-
-template <int KH, int KW, int S, int OH, int OW>
 struct DgradEpi {  // (m = c, n = pos) -> dX[b, c, iy, ix] = acc * (X[b,c,iy,ix] > 0 if relu_gate)
     using G = DgradGeom<KH, KW, S, OH, OW>;
-    float* dx; const float* xact; int C; int NP; int py, px;
+    float* dx; const float* xact; int C; int NP;
     struct Col { long off; int ok; };
     __device__ __forceinline__ Col col(int n) const {
+        const int py = (int)blockIdx.z / S, px = (int)blockIdx.z % S;              // stride phase = grid z
         Col c; c.ok = n < NP; const int nn = c.ok ? n : 0;
         const int b = nn / G::JP, j = nn % G::JP;
         const int iy = S * (j / G::JW) + py, ix = S * (j % G::JW) + px;
@@ -207,6 +181,88 @@ struct DgradEpi {  // (m = c, n = pos) -> dX[b, c, iy, ix] = acc * (X[b,c,iy,ix]
         float v = acc;
         if (xact) v = xact[o] > 0.f ? v : 0.f;
         dx[o] = v;
+    }
+};
+
+
+// ==========================================================================================
+// Position-contiguous ("Pos") operands for stride-1 access patterns.
+// A vector-memory instruction costs the same issue slots whether it moves 4 or 16 bytes per lane, and the
+// scalar gathers of the generic im2col / dgrad loaders are what bounds those kernels.  For a stride-1 window,
+// consecutive output positions read consecutive pixels, so the loaders below fetch FOUR positions with one
+// 4-byte-aligned global_load_dwordx4.  Rows of the position space are padded to a multiple of 4 (OWP / JWP);
+// padding positions are dropped by the epilogue (forward, dgrad) or multiplied by an exact zero from the
+// other operand (wgrad).
+// ==========================================================================================
+__device__ __forceinline__ f32x4 load4_unaligned(const float* q, const float* lo, const float* hi) {
+    if (q >= lo && q + 4 <= hi) return *reinterpret_cast<const f32x4_u*>(q);
+    f32x4 v = zero4();                                   // tensor edge: guarded scalar loads
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (q + j >= lo && q + j < hi) v[j] = q[j];
+    return v;
+}
+
+// stride-1 im2col: element (kk = (c,ky,kx), padded position pp = (b, oy, oxp))
+template <int KH, int KW, int H, int W, int OWP, bool INNER_K>
+struct Im2colPos {
+    static constexpr bool INNER_IS_K = INNER_K;          // true: positions are the GEMM K (wgrad); false: rows (fwd)
+    static constexpr int OH = H - KH + 1, OW = W - KW + 1, PP = OH * OWP, KK = KH * KW, HW = H * W;
+    static_assert(OWP % 4 == 0 && OWP >= OW, "padded row length");
+    const float* x; const float* x_end; int C; int RP; int Kc;
+    struct Outer { int off; int ok; };
+    __device__ __forceinline__ Outer prep(int kk) const {
+        Outer o; o.ok = kk < Kc; const int k = o.ok ? kk : 0;
+        const int c = k / KK, rem = k % KK;
+        o.off = c * HW + (rem / KW) * W + (rem % KW);
+        return o;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, int p0) const {
+        if (!o.ok || p0 >= RP) return zero4();
+        const int b = p0 / PP, r = p0 % PP;
+        const float* q = x + (long)b * C * HW + o.off + (r / OWP) * W + (r % OWP);
+        return load4_unaligned(q, x, x_end);
+    }
+};
+
+// Y / dY [B, OC, OH*OW] viewed as (oc, padded position); exact zeros at padding positions
+template <int OH, int OW, int OWP>
+struct ConvOutPos {
+    static constexpr bool INNER_IS_K = true;
+    static constexpr int SP = OH * OW, PP = OH * OWP;
+    const float* p; const float* p_end; int OC; int RP;
+    struct Outer { const float* cp; int ok; };
+    __device__ __forceinline__ Outer prep(int oc) const {
+        Outer o; o.ok = oc < OC; o.cp = p + (long)(o.ok ? oc : 0) * SP; return o;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, int p0) const {
+        if (!o.ok || p0 >= RP) return zero4();
+        const int b = p0 / PP, r = p0 % PP;
+        const int oy = r / OWP, ox0 = r % OWP;
+        if (ox0 >= OW) return zero4();
+        f32x4 v = load4_unaligned(o.cp + (long)b * OC * SP + oy * OW + ox0, p, p_end);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (ox0 + j >= OW) v[j] = 0.f;
+        return v;
+    }
+};
+
+template <int OH, int OW, int OWP>
+struct ConvFwdEpiPos {   // (m = oc, n = padded position) -> Y[b, oc, oy, ox]
+    static constexpr int SP = OH * OW, PP = OH * OWP;
+    float* y; const float* bias; int OC; int RP; float scale; int relu;
+    struct Col { long off; int ok; };
+    __device__ __forceinline__ Col col(int n) const {
+        Col c; c.ok = n < RP; const int nn = c.ok ? n : 0;
+        const int b = nn / PP, r = nn % PP;
+        const int oy = r / OWP, ox = r % OWP;
+        if (ox >= OW) c.ok = 0;
+        c.off = (long)b * OC * SP + oy * OW + ox; return c;
+    }
+    __device__ __forceinline__ void st(const Col& c, int m, float acc, int) const {
+        if (!c.ok || m >= OC) return;
+        float v = acc * scale + (bias ? bias[m] : 0.f);
+        if (relu) v = v > 0.f ? v : 0.f;
+        y[c.off + (long)m * SP] = v;
     }
 };
 

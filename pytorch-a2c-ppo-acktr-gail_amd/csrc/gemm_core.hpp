@@ -48,7 +48,9 @@ struct OperandTile {
     static constexpr int PITCH_R = BR + 4;
     static constexpr int SMEM = Op::INNER_IS_K ? BR * PK : GK * PITCH_R;
     static constexpr int RQ = BR / 4;                // row-contiguous layout: float4 groups per k row
-    static constexpr int KSTEP = 256 / RQ;
+    // row-contiguous mapping: thread -> ONE k row (tid / 8) and UNITS row groups (tid % 8 + 8u), so the outer
+    // state of that k (an im2col position decode + gather-index load) is prepared once per thread per K tile
+    static_assert(RQ % 8 == 0, "row tile must be a multiple of 32");
 
     f32x4 regs[UNITS];
     typename Op::Outer outer[Op::INNER_IS_K ? UNITS : 1];
@@ -65,10 +67,9 @@ struct OperandTile {
 #pragma unroll
             for (int u = 0; u < UNITS; ++u) regs[u] = op.ld4(outer[u], k0);
         } else {
-            const int r0 = row_base + 4 * (tid % RQ);
-            const int k = k_base + tid / RQ;
+            const typename Op::Outer o = op.prep(k_base + (tid >> 3));
 #pragma unroll
-            for (int u = 0; u < UNITS; ++u) regs[u] = op.ld4(op.prep(k + KSTEP * u), r0);
+            for (int u = 0; u < UNITS; ++u) regs[u] = op.ld4(o, row_base + 4 * ((tid & 7) + 8 * u));
         }
     }
     __device__ __forceinline__ void store(float* s, int tid) const {
@@ -79,7 +80,7 @@ struct OperandTile {
         } else {
 #pragma unroll
             for (int u = 0; u < UNITS; ++u)
-                *reinterpret_cast<f32x4*>(s + (tid / RQ + KSTEP * u) * PITCH_R + 4 * (tid % RQ)) = regs[u];
+                *reinterpret_cast<f32x4*>(s + (tid >> 3) * PITCH_R + 4 * ((tid & 7) + 8 * u)) = regs[u];
         }
     }
     // fragment for tile-local row `row`, k group base kk = 8q + 4h
@@ -102,7 +103,7 @@ struct OperandTile {
 //   struct Col;  Col col(int n) const;                       // per-lane column state (validity, offsets)
 //   void st(const Col&, int m, float acc, int kslice) const; // bounds-checks m itself
 // ------------------------------------------------------------------------------------------
-template <int BM, int BN, int WM, int WN, class MOp, class NOp, class Epi>
+template <int BM, int BN, int WM, int WN, class MOp, class NOp, class Epi, bool ZBATCH = false>
 __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const NOp nop, const Epi epi, int K,
                                                             int kchunk) {
     static_assert(WM * WN == 4, "4 waves per workgroup");
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
-    const int kbeg = blockIdx.z * kchunk;
+    const int kbeg = ZBATCH ? 0 : blockIdx.z * kchunk;     // ZBATCH: z is a phase index the functors read themselves
     int kend = kbeg + kchunk;
     if (kend > K) kend = K;
     const int nk = (kend - kbeg + GK - 1) / GK;
@@ -220,6 +221,31 @@ int launch_gemm(const MOp& mop, const NOp& nop, const Epi& epi, int M, int N, in
         set_error("gemm grid too large (%u,%u,%u)", grid.x, grid.y, grid.z);
         return -1;
     }
+    hipLaunchKernelGGL(kern, grid, dim3(256), smem_bytes, stream, mop, nop, epi, K, kchunk);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+// Same skeleton with blockIdx.z as a batch / phase index (functors read blockIdx.z); K is not split.
+template <int BM, int BN, int WM, int WN, class MOp, class NOp, class Epi>
+int launch_gemm_z(const MOp& mop, const NOp& nop, const Epi& epi, int M, int N, int K, int nz, hipStream_t stream) {
+    using MT = OperandTile<BM, MOp>;
+    using NT = OperandTile<BN, NOp>;
+    constexpr int smem_bytes = 2 * (MT::SMEM + NT::SMEM) * (int)sizeof(float);
+    if (M <= 0 || N <= 0 || nz <= 0) return 0;
+    int kchunk = ((K + GK - 1) / GK) * GK;
+    auto kern = gemm_mfma_f32_kernel<BM, BN, WM, WN, MOp, NOp, Epi, true>;
+    if (smem_bytes > 48 * 1024) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+            attr_set = true;
+        }
+    }
+    dim3 grid(cdiv(N, BN), cdiv(M, BM), nz);
+    if (grid.y > 65535 || grid.z > 65535) { set_error("gemm grid too large"); return -1; }
     hipLaunchKernelGGL(kern, grid, dim3(256), smem_bytes, stream, mop, nop, epi, K, kchunk);
     ACKTR_LAUNCH_CHECK();
     return 0;

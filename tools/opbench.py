@@ -1,0 +1,84 @@
+"""Standalone timing of the NatureCNN update-path ops at the bench minibatch size (B=1024).
+
+    python tools/opbench.py [--ops conv4s2_dgrad,conv3s1_fwd] [--iters 50] [--batch 1024]
+
+Each op is launched `iters` times back to back on the current stream and timed with HIP events;
+meant to be run under `rocprofv3 --kernel-trace --stats` or `--pmc` for per-kernel counters.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'pytorch-a2c-ppo-acktr-gail_amd'))
+
+from a2c_ppo_acktr import ops  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--ops', default='')
+    ap.add_argument('--iters', type=int, default=50)
+    ap.add_argument('--batch', type=int, default=1024)
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    B = a.batch
+    g = torch.Generator(device='cpu').manual_seed(1)
+    rn = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x0 = (torch.rand(B, 4, 84, 84, generator=g) * 255).to(dev)
+    w1, b1 = rn(32, 4, 8, 8) * 0.05, rn(32) * 0.1
+    w2, b2 = rn(64, 32, 4, 4) * 0.05, rn(64) * 0.1
+    w3, b3 = rn(32, 64, 3, 3) * 0.05, rn(32) * 0.1
+    wf, bf = rn(512, 1568) * 0.02, rn(512) * 0.1
+    wh, bh = rn(7, 512) * 0.05, rn(7) * 0.1
+    a1 = ops.conv2d_fwd(x0, w1, b1, 4, in_scale=1 / 255.0)
+    a2 = ops.conv2d_fwd(a1, w2, b2, 2)
+    a3 = ops.conv2d_fwd(a2, w3, b3, 1)
+    h = ops.linear_fwd(a3.view(B, -1), wf, bf, act='relu')
+    dy1, dy2, dy3 = rn(*a1.shape), rn(*a2.shape), rn(*a3.shape)
+    dh, dhead = rn(B, 512), rn(B, 7)
+    dw1, dw2, dw3 = torch.empty_like(w1), torch.empty_like(w2), torch.empty_like(w3)
+    db1, db2, db3 = torch.empty_like(b1), torch.empty_like(b2), torch.empty_like(b3)
+    dwf, dbf, dwh, dbh = torch.empty_like(wf), torch.empty_like(bf), torch.empty_like(wh), torch.empty_like(bh)
+    o1, o2, o3 = torch.empty_like(a1), torch.empty_like(a2), torch.empty_like(a3)
+    oh, ohead = torch.empty_like(h), torch.empty(B, 7, device=dev)
+    dx2, dx3, dxf, dxh = torch.empty_like(a1), torch.empty_like(a2), torch.empty(B, 1568, device=dev), torch.empty_like(h)
+    table = {
+        'conv8s4_fwd': (lambda: ops.conv2d_fwd(x0, w1, b1, 4, in_scale=1 / 255.0, out=o1), 2.0 * a1.numel() * 4 * 64),
+        'conv4s2_fwd': (lambda: ops.conv2d_fwd(a1, w2, b2, 2, out=o2), 2.0 * a2.numel() * 32 * 16),
+        'conv3s1_fwd': (lambda: ops.conv2d_fwd(a2, w3, b3, 1, out=o3), 2.0 * a3.numel() * 64 * 9),
+        'fc_fwd': (lambda: ops.linear_fwd(a3.view(B, -1), wf, bf, act='relu', out=oh), 2.0 * B * 1568 * 512),
+        'head_fwd': (lambda: ops.linear_fwd(h, wh, bh, out=ohead), 2.0 * B * 512 * 7),
+        'head_dgrad': (lambda: ops.linear_dgrad(dhead, wh, gate_src=h, gate='relu', out=dxh), 2.0 * B * 512 * 7),
+        'head_wgrad': (lambda: ops.linear_wgrad(dhead, h, dwh, dbh), 2.0 * B * 512 * 7),
+        'fc_dgrad': (lambda: ops.linear_dgrad(dh, wf, gate_src=a3.view(B, -1), gate='relu', out=dxf), 2.0 * B * 1568 * 512),
+        'fc_wgrad': (lambda: ops.linear_wgrad(dh, a3.view(B, -1), dwf, dbf), 2.0 * B * 1568 * 512),
+        'conv3s1_dgrad': (lambda: ops.conv2d_dgrad(dy3, w3, a2, 1, out=dx3), 2.0 * a3.numel() * 64 * 9),
+        'conv3s1_wgrad': (lambda: ops.conv2d_wgrad(a2, dy3, w3.shape, 1, dw3, db3), 2.0 * a3.numel() * 64 * 9),
+        'conv4s2_dgrad': (lambda: ops.conv2d_dgrad(dy2, w2, a1, 2, out=dx2), 2.0 * a2.numel() * 32 * 16),
+        'conv4s2_wgrad': (lambda: ops.conv2d_wgrad(a1, dy2, w2.shape, 2, dw2, db2), 2.0 * a2.numel() * 32 * 16),
+        'conv8s4_wgrad': (lambda: ops.conv2d_wgrad(x0, dy1, w1.shape, 4, dw1, db1, in_scale=1 / 255.0), 2.0 * a1.numel() * 4 * 64),
+    }
+    names = [n for n in a.ops.split(',') if n] or list(table)
+    tot = 0.0
+    for n in names:
+        fn, flop = table[n]
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        tot += ms
+        print('%-16s %8.2f us  %7.2f TF' % (n, ms * 1e3, flop / ms * 1e-9), flush=True)
+    print('total %.1f us' % (tot * 1e3))
+
+
+if __name__ == '__main__':
+    main()

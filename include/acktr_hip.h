@@ -60,10 +60,13 @@ int acktr_gather_rows(const void* src, const int64_t* idx, void* dst, long rows,
  * y[B,OC,OH,OW] = relu?( in_scale * conv(x, w) + bias ), NCHW, no padding.  Supported geometries:
  * (H=W=84,K=8,S=4), (H=W=20,K=4,S=2), (H=W=9,K=3,S=1); any C, OC.  in_scale folds `inputs / 255.0`.
  * gather_idx (nullable, int64[B]): image b is read from x + gather_idx[b]*C*H*W -- the minibatch
- * gather of storage.py:127 fused into the loader.  x, w 16-byte aligned. */
+ * gather of storage.py:127 fused into the loader.  x, w 16-byte aligned.  `workspace` (nullable, 16-byte
+ * aligned, ..._workspace_bytes) holds the weights re-ordered for the LDS-stationary kernel; without it the
+ * generic tile-GEMM kernel runs. */
+long acktr_conv2d_fwd_workspace_bytes(int C, int H, int W, int OC, int KH, int KW, int S);
 int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
                          int B, int C, int H, int W, int OC, int KH, int KW, int S, float in_scale, int relu,
-                         void* stream);
+                         void* workspace, long workspace_bytes, void* stream);
 
 /* autograd backward of the same Conv2d w.r.t. weight and bias: dw[OC,C,KH,KW] = in_scale * sum dy (x) patches,
  * db[OC] = sum dy (db nullable).  Split-K slabs live in `workspace` (see ..._workspace_bytes); the
@@ -75,8 +78,8 @@ int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const floa
 
 /* autograd backward w.r.t. the input: dx[B,C,H,W] = conv_transpose(dy, w) (* (x_act > 0) when x_act is
  * given: the ReLU backward of the layer that produced x, model.py:177-179).  `workspace` (16-byte aligned,
- * ..._workspace_bytes) receives the weights re-packed per stride phase for 16-byte operand streaming. */
-long acktr_conv2d_dgrad_workspace_bytes(int C, int OC, int KH, int KW, int S);
+ * ..._workspace_bytes) receives the re-ordered weights and the zero-padded copy of dy. */
+long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, int OC, int KH, int KW, int S);
 int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
                            int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, void* stream);
 

@@ -43,10 +43,11 @@ _PROTOS = {
     'acktr_adv_normalize_workspace_bytes': (c_l, []),
     'acktr_adv_normalize_f32': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p]),
     'acktr_gather_rows': (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
-    'acktr_conv2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_i, c_p]),
+    'acktr_conv2d_fwd_workspace_bytes': (c_l, [c_i] * 7),
+    'acktr_conv2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_i, c_p, c_l, c_p]),
     'acktr_conv2d_wgrad_workspace_bytes': (c_l, [c_i] * 8),
     'acktr_conv2d_wgrad_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_p, c_l, c_p]),
-    'acktr_conv2d_dgrad_workspace_bytes': (c_l, [c_i] * 5),
+    'acktr_conv2d_dgrad_workspace_bytes': (c_l, [c_i] * 8),
     'acktr_conv2d_dgrad_f32': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_l, c_p]),
     'acktr_linear_fwd_workspace_bytes': (c_l, [c_i, c_i, c_i]),
     'acktr_linear_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p]),

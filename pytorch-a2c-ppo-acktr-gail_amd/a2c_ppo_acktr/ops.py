@@ -78,10 +78,14 @@ def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out
     if out is None:
         out = torch.empty(B, OC, OH, OW, dtype=f32, device=x.device)
     assert out.shape == (B, OC, OH, OW)
+    L = _hip.lib()
+    nb = L.acktr_conv2d_fwd_workspace_bytes(C, H, W, OC, KH, KW, stride)
+    ws = workspace(x.device, nb, tag='convfwd') if nb else None
     with _Timed('conv%ds%d_fwd' % (KH, stride), 2.0 * B * OH * OW * OC * C * KH * KW):
-        rc = _hip.lib().acktr_conv2d_fwd_f32(
+        rc = L.acktr_conv2d_fwd_f32(
             _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
-            B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0, _hip.cur_stream(x.device))
+            B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0,
+            _p(ws, 'workspace', torch.uint8), ws.numel() if ws is not None else 0, _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_conv2d_fwd_f32')
     return out
 
@@ -116,7 +120,7 @@ def conv2d_dgrad(dy, w, x_act, stride, out=None):
         out = torch.empty(B, C, H, W, dtype=f32, device=dy.device)
     assert out.shape == (B, C, H, W) and (x_act is None or x_act.shape == out.shape)
     L = _hip.lib()
-    ws = workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(C, OC, KH, KW, stride), tag='dgrad')
+    ws = workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride), tag='dgrad')
     with _Timed('conv%ds%d_dgrad' % (KH, stride), 2.0 * dy.numel() * C * KH * KW):
         rc = L.acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
                                       B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),

@@ -3,6 +3,7 @@
 // their autograd backward.  Supported geometries are the policy's three layers:
 //   8x8 stride 4 on 84x84, 4x4 stride 2 on 20x20, 3x3 stride 1 on 9x9 (any channel counts).
 #include "conv_ops.hpp"
+#include "conv_sw.hpp"
 #include "../../include/acktr_hip.h"
 
 namespace acktr {
@@ -170,6 +171,43 @@ static int conv_dgrad_t(const float* dy, const float* w, const float* xact, floa
     DgradEpi<KH, KW, S, OH, OW> epi{dx, xact, C, NP};
     return launch_gemm_z<BM, 128, WM, WN>(wop, gop, epi, C, NP, Kred, S * S, s);
 }
+
+int sw_num_cus() {
+    static int cus[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (cus[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus[dev] = n;
+    }
+    return cus[dev];
+}
+
+// stationary-weight geometries (conv_sw.hpp): forward of the three layers, dgrad of layers 3 and 2
+// (channel counts are those of the reference's CNNBase, model.py:176-179; other counts take the tile-GEMM path)
+using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, 8, HM_KX>;
+using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, 8, HM_KY>;
+using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, 12, HM_CH>;
+using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 12, HM_CH>;    // padded 7x7 dY, flipped 3x3 kernel
+using SwD2 = SwGeom<2, 2, 1, 11, 11, 64, 4, 2, 8, HM_CH>;     // padded 9x9 dY, four 2x2 phase kernels stacked along M
+
+static long sw_fwd_image_bytes(int geom, int C, int OC) {
+    if (geom == GEOM_8S4 && SwF1::ok(C, OC)) return SwF1::lds_bytes();
+    if (geom == GEOM_4S2 && SwF2::ok(C, OC)) return SwF2::lds_bytes();
+    if (geom == GEOM_3S1 && SwF3::ok(C, OC)) return SwF3::lds_bytes();
+    return 0;
+}
+// dgrad through the stationary kernel: C = channels of dX, OC = channels of dY (the reduction)
+static bool sw_dgrad_ok(int geom, int C, int OC) {
+    if (geom == GEOM_4S2) return C == 32 && SwD2::ok(OC, 128);
+    if (geom == GEOM_3S1) return SwD3::ok(OC, C);
+    return false;
+}
+static long sw_dgrad_image_floats(int geom, int OC) {
+    return geom == GEOM_4S2 ? SwD2::image_floats() : SwD3::image_floats();
+}
+static long sw_dgrad_pad_floats(int geom, int B, int OC) { return (long)B * OC * 121 + 4; }
 }  // namespace acktr
 
 using namespace acktr;
@@ -182,14 +220,43 @@ using namespace acktr;
               H, W, KH, KW, S);                                                                               \
     ACKTR_ARG((long)B * C * H * W < (1L << 31) || gather_ok, name ": tensor too large for 32-bit positions")
 
+extern "C" long acktr_conv2d_fwd_workspace_bytes(int C, int H, int W, int OC, int KH, int KW, int S) {
+    const int geom = geom_of(H, W, KH, KW, S);
+    if (geom == GEOM_NONE || C <= 0 || OC <= 0) return 0;
+    return sw_fwd_image_bytes(geom, C, OC);
+}
+
 extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias,
                                     float* y, int B, int C, int H, int W, int OC, int KH, int KW, int S,
-                                    float in_scale, int relu, void* stream) {
+                                    float in_scale, int relu, void* workspace, long workspace_bytes, void* stream) {
     ACKTR_ARG(x && w && y, "conv2d_fwd: null pointer");
     const bool gather_ok = true;
     CONV_COMMON_CHECKS("conv2d_fwd");
     ACKTR_ARG(((uintptr_t)x & 15) == 0 && ((uintptr_t)w & 15) == 0, "conv2d_fwd: x and w must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    // stationary-weight path (needs the weight-image workspace); the tile-GEMM path below covers everything else
+    const long img_bytes = sw_fwd_image_bytes(geom, C, OC);
+    if (img_bytes > 0 && workspace && workspace_bytes >= img_bytes && ((uintptr_t)workspace & 15) == 0 &&
+        (long)B * OC * 400 < (1L << 31)) {
+        float* img = (float*)workspace;
+        int rc;
+        if (geom == GEOM_8S4) {
+            rc = launch_sw_pack<SwF1>(w, img, OC, 0, 0, 0, s);
+            if (rc) return rc;
+            SwFwdEpi<SwF1::SP> epi{y, bias, OC, in_scale, relu};
+            return launch_conv_sw<SwF1>(x, gather_idx, img, epi, B * SwF1::SP, s);
+        }
+        if (geom == GEOM_4S2) {
+            rc = launch_sw_pack<SwF2>(w, img, OC, 0, 0, 0, s);
+            if (rc) return rc;
+            SwFwdEpi<SwF2::SP> epi{y, bias, OC, in_scale, relu};
+            return launch_conv_sw<SwF2>(x, gather_idx, img, epi, B * SwF2::SP, s);
+        }
+        rc = launch_sw_pack<SwF3>(w, img, OC, 0, 0, 0, s);
+        if (rc) return rc;
+        SwFwdEpi<SwF3::SP> epi{y, bias, OC, in_scale, relu};
+        return launch_conv_sw<SwF3>(x, gather_idx, img, epi, B * SwF3::SP, s);
+    }
     if (geom == GEOM_8S4) {
         if (OC <= 32) return conv_fwd_t<8, 8, 4, 84, 84, 32, 1, 4>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
         return conv_fwd_t<8, 8, 4, 84, 84, 64, 2, 2>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
@@ -237,15 +304,21 @@ extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx,
     return conv_wgrad_pos_t<3, 3, 9, 9, 8, 64, 2, 2>(x, dy, dw, db, B, C, OC, in_scale, ws, wf, s);
 }
 
-static long dgrad_ws_floats(int C, int OC, int KH, int KW, int S) {
+static long dgrad_ws_floats(int B, int C, int H, int W, int OC, int KH, int KW, int S) {
     const int taps = ((KH + S - 1) / S) * ((KW + S - 1) / S);
     const long kredp = ((long)OC * taps + 3) / 4 * 4;
-    return (long)S * S * C * kredp;
+    long n = (long)S * S * C * kredp;                                   // tile-GEMM path: per-phase packed weights
+    const int geom = geom_of(H, W, KH, KW, S);
+    if (sw_dgrad_ok(geom, C, OC)) {                                    // stationary path: weight image + padded dY
+        const long m = sw_dgrad_image_floats(geom, OC) + sw_dgrad_pad_floats(geom, B, OC);
+        if (m > n) n = m;
+    }
+    return n;
 }
 
-extern "C" long acktr_conv2d_dgrad_workspace_bytes(int C, int OC, int KH, int KW, int S) {
-    if (C <= 0 || OC <= 0 || KH <= 0 || KW <= 0 || S <= 0) return 0;
-    return dgrad_ws_floats(C, OC, KH, KW, S) * (long)sizeof(float);
+extern "C" long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, int OC, int KH, int KW, int S) {
+    if (B <= 0 || C <= 0 || OC <= 0 || KH <= 0 || KW <= 0 || S <= 0) return 0;
+    return dgrad_ws_floats(B, C, H, W, OC, KH, KW, S) * (long)sizeof(float);
 }
 
 extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C,
@@ -254,11 +327,31 @@ extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const flo
     ACKTR_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     const bool gather_ok = false;
     CONV_COMMON_CHECKS("conv2d_dgrad");
-    ACKTR_ARG(workspace && workspace_bytes >= dgrad_ws_floats(C, OC, KH, KW, S) * (long)sizeof(float),
+    ACKTR_ARG(workspace && workspace_bytes >= dgrad_ws_floats(B, C, H, W, OC, KH, KW, S) * (long)sizeof(float),
               "conv2d_dgrad: workspace too small (%ld bytes given)", workspace_bytes);
     ACKTR_ARG(((uintptr_t)workspace & 15) == 0, "conv2d_dgrad: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     float* wp = (float*)workspace;
+    if (sw_dgrad_ok(geom, C, OC) && (long)B * OC * 121 < (1L << 31)) {
+        float* img = wp;
+        float* dyp = wp + sw_dgrad_image_floats(geom, OC);
+        const long planes = (long)B * OC;
+        const unsigned pgrid = (unsigned)((planes + 7) / 8);
+        if (geom == GEOM_4S2) hipLaunchKernelGGL((sw_pad_kernel<9, 9, 1>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
+        else hipLaunchKernelGGL((sw_pad_kernel<7, 7, 2>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
+        ACKTR_LAUNCH_CHECK();
+        int rc;
+        if (geom == GEOM_4S2) {
+            rc = launch_sw_pack<SwD2>(w, img, 4 * C, 1, C, 2, s);
+            if (rc) return rc;
+            SwPhase2Epi<10, 10, 20, 20> epi{dx, x_act};
+            return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s);
+        }
+        rc = launch_sw_pack<SwD3>(w, img, C, 1, C, 1, s);
+        if (rc) return rc;
+        SwGateEpi<81> epi{dx, x_act, C};
+        return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s);
+    }
 #define DG(KH_, KW_, S_, OH_, OW_)                                                                 \
     (C <= 32 ? conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 32, 1, 4>(dy, w, x_act, dx, B, C, OC, wp, s)   \
              : conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 64, 2, 2>(dy, w, x_act, dx, B, C, OC, wp, s))

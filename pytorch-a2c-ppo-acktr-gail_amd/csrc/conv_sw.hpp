@@ -1,0 +1,392 @@
+// Stationary-weight convolution kernel (gfx950): forward and dgrad of the policy's conv layers.
+//
+//   out(m, r) = sum_{c, ky, kx} Wm(m; c, ky, kx) * X[img(r), c, S*oy(r) + ky, S*ox(r) + kx]
+//
+// The GEMM is tall and skinny the "wrong" way round: M (output channels, 32..128) is tiny, N (positions,
+// ~10^5) is huge, K (256..576) moderate.  So the WEIGHTS (<= 128 KB) stay in LDS for the lifetime of a
+// workgroup, pre-permuted into MFMA A-fragment order, and the position operand never touches LDS: each lane
+// loads the 2..4 contiguous kernel-row taps of ITS position straight from global memory into the register
+// that the MFMA consumes (the B operand of v_mfma_f32_32x32x2_f32 wants lane -> column anyway).  Consequences:
+//   * no barrier in the main loop: the waves of a workgroup stream independent 32-position tiles
+//   * one 8/12/16-byte global load + TM LDS reads per E*TM MFMAs, and almost no address arithmetic
+//     (lane base pointer per tile; every chunk offset is a compile-time constant)
+//   * every activation is fetched exactly once per tap row by exactly one lane
+// K order: the reduction index is split into "chunks" (c, ky, 4-wide piece of kx); the MFMA's two k-lanes
+// (lane halves h = 0, 1) take the two chunks of a chunk PAIR, which differ by a constant address offset (see
+// the HM_* modes), so both halves use the same constants and differ only in their base pointer.  Sums are fp32
+// FMA chains in a fixed order.
+//
+// dgrad runs through the same kernel: dX of a stride-S layer is S*S stride-1 correlations of the zero-padded
+// dY with (KH/S x KW/S) sub-kernels; the S*S phases share the position operand and are stacked along M, so a
+// lane ends up holding horizontally adjacent dX pixels and stores them as one 8-byte write.
+#pragma once
+#include "gemm_core.hpp"
+
+namespace acktr {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+template <int E> struct TapVec;
+template <> struct TapVec<2> { typedef f32x2 type; typedef f32x2 utype __attribute__((aligned(4))); };
+template <> struct TapVec<3> { typedef f32x3 type; typedef f32x3 utype __attribute__((aligned(4))); };
+template <> struct TapVec<4> { typedef f32x4 type; typedef f32x4 utype __attribute__((aligned(4))); };
+
+// How the MFMA's two k-lanes (lane halves h = 0, 1) split a chunk pair:
+//   HM_CH: h picks the channel half (c = cp + h*C/2)         any kernel
+//   HM_KX: h picks the 4-wide piece of an 8-wide kernel row   (both halves of a load hit the same cache lines)
+//   HM_KY: h picks the parity of the kernel row ky = 2*kyp+h  (adjacent rows: mostly the same cache lines)
+// Chunk pairs are ordered CHANNEL-FASTEST: j = g*CP + cp (g = kernel row group, cp = channel).  Consecutive loads
+// of a lane then touch different channel planes, and the next kernel row of the same plane -- which lives in the
+// same 128-byte lines -- is requested CP loads later, when the line has arrived.  (With the rows of one channel
+// requested back to back the L1 sat in hit-on-miss stalls for 2/3 of the kernel: TCP_PENDING_STALL_CYCLES.)
+enum { HM_CH = 0, HM_KX = 1, HM_KY = 2 };
+
+// NT_ threads per workgroup (one workgroup per CU): 512 -> 2 waves per SIMD with a 256-register budget.
+// CH_ input channels are compile time too: the chunk loop is fully unrolled, which makes every chunk offset a
+// constant and lets the compiler count outstanding loads exactly (a run-time stage loop made it drain the
+// prefetch with s_waitcnt vmcnt(0) at every loop header).
+// TM_ 32-row M blocks are resident in LDS; one work item (a wave's unit of work) is a 32-position tile times
+// TMW_ of them.  TMW_ < TM_ re-reads the activations TM_/TMW_ times (from L1/L2) but makes the items small
+// enough to balance: at minibatch 1024 there are only 1.3 - 1.6 full tiles per wave.
+template <int KH_, int KW_, int S_, int H_, int W_, int CH_, int TM_, int TMW_, int NL_, int HM_, int NT_ = 512>
+struct SwGeom {
+    static constexpr int KH = KH_, KW = KW_, S = S_, H = H_, W = W_, CH = CH_, TM = TM_, NL = NL_, HM = HM_;
+    static constexpr int TMW = TMW_, MG = TM_ / TMW_;
+    static_assert(TM_ % TMW_ == 0, "M blocks per work item");
+    static constexpr int NT = NT_, NWAVES = NT_ / 64;
+    static_assert(KW <= 4 || KW % 4 == 0, "kernel rows are cut into 4-wide chunks");
+    static constexpr int NKXC = (KW + 3) / 4;           // chunks per kernel row
+    static constexpr int E = KW >= 4 ? 4 : KW;          // taps per chunk (= MFMA k-steps per chunk)
+    static constexpr int EP = E == 3 ? 4 : E;           // floats per LDS fragment slot
+    static constexpr int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1, SP = OH * OW, HW = H * W;
+    static_assert(HM != HM_CH || CH % 2 == 0, "channel halves");
+    static_assert(HM != HM_KX || NKXC == 2, "kx halves need an 8-wide kernel row");
+    static_assert(HM != HM_KY || KH % 2 == 0, "ky parity needs an even kernel height");
+    static constexpr int CP = HM == HM_CH ? CH / 2 : CH;                                   // channels per row group
+    static constexpr int NG = HM == HM_CH ? KH * NKXC : (HM == HM_KX ? KH : (KH / 2) * NKXC);   // row groups
+    static constexpr int J = NG * CP;                                                      // chunk pairs
+    static constexpr int HOFF = HM == HM_CH ? (CH / 2) * HW : (HM == HM_KX ? 4 : W);       // h = 1 lanes' extra offset
+    // element offset (floats, h = 0) of chunk pair j relative to the lane's window origin
+    __host__ __device__ static constexpr int off0(int j) {
+        const int g = j / CP, cp = j % CP;
+        return cp * HW + (HM == HM_CH ? (g / NKXC) * W + (g % NKXC) * 4
+                                      : (HM == HM_KX ? g * W : 2 * (g / NKXC) * W + (g % NKXC) * 4));
+    }
+    // (c, ky, kx0) of chunk pair j for half h  (used by the weight packer)
+    __host__ __device__ static constexpr int dec_c(int j, int h) { return j % CP + (HM == HM_CH ? h * (CH / 2) : 0); }
+    __host__ __device__ static constexpr int dec_ky(int j, int h) {
+        const int g = j / CP;
+        return HM == HM_CH ? g / NKXC : (HM == HM_KX ? g : 2 * (g / NKXC) + h);
+    }
+    __host__ __device__ static constexpr int dec_kx0(int j, int h) {
+        const int g = j / CP;
+        return HM == HM_KX ? 4 * h : (g % NKXC) * 4;
+    }
+    static_assert(J % (2 * NL) == 0, "even number of stages (the two activation buffers alternate across tiles)");
+    static_assert(J % 4 == 0, "A-fragment ring slots must line up across tiles");
+    static constexpr int NS = J / NL;
+    static constexpr long IMAGE_FLOATS = (long)J * TM * 64 * EP;
+    static_assert(IMAGE_FLOATS * 4 <= 160 * 1024, "weights must fit in LDS");
+    static bool ok(int C, int M) { return C == CH && M <= TM * 32; }
+    __host__ __device__ static constexpr long image_floats() { return IMAGE_FLOATS; }
+    static constexpr long lds_bytes() { return IMAGE_FLOATS * 4; }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// weight image: float index (((j*TM + a)*2 + h)*32 + li)*EP + t  holds  Wm(m = 32a+li; chunk pair j, half h, tap t)
+//   mode 0 (forward): Wm(m; c,ky,kx) = w[m][c][ky][kx]                                   w: [OC][C][KH][KW]
+//   mode 1 (dgrad)  : m = (py*SD+px)*CX + cx,  c = oc,
+//                     Wm = w[oc][cx][py + SD*(KH-1-ky)][px + SD*(KW-1-kx)]               w: [OC][CX][KH*SD][KW*SD]
+// ---------------------------------------------------------------------------------------------------
+template <class G>
+__global__ __launch_bounds__(256) void sw_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ img,
+                                                              int M, int mode, int CX, int SD) {
+    constexpr long n = G::image_floats();
+    constexpr int C = G::CH;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int t = (int)(i % G::EP);
+        long q = i / G::EP;
+        const int li = (int)(q % 32); q /= 32;
+        const int h = (int)(q % 2); q /= 2;
+        const int a = (int)(q % G::TM);
+        const int j = (int)(q / G::TM);
+        const int m = 32 * a + li;
+        const int c = G::dec_c(j, h), ky = G::dec_ky(j, h), kx = G::dec_kx0(j, h) + t;
+        float v = 0.f;
+        if (m < M && t < G::E && kx < G::KW) {
+            if (mode == 0) {
+                v = w[(((long)m * C + c) * G::KH + ky) * G::KW + kx];
+            } else {
+                const int ph = m / CX, cx = m % CX;
+                const int py = ph / SD, px = ph % SD;
+                const int wy = py + SD * (G::KH - 1 - ky), wx = px + SD * (G::KW - 1 - kx);
+                v = w[(((long)c * CX + cx) * (G::KH * SD) + wy) * (G::KW * SD) + wx];
+            }
+        }
+        img[i] = v;
+    }
+}
+
+// zero-padded copy dyp[pl][y+P][x+P] = dy[pl][y][x]  (planes OH x OW -> HP x WP); 8 planes per workgroup,
+// compile-time plane geometry so the index split is multiply-shift
+template <int OH, int OW, int P>
+__global__ __launch_bounds__(256) void sw_pad_kernel(const float* __restrict__ dy, float* __restrict__ dyp, long planes) {
+    constexpr int HP = OH + 2 * P, WP = OW + 2 * P, PP = HP * WP, PPB = 8;
+    const long pl0 = (long)blockIdx.x * PPB;
+    for (int i = threadIdx.x; i < PPB * PP; i += 256) {
+        const int pl = i / PP, e = i % PP;
+        if (pl0 + pl >= planes) break;
+        const int yy = e / WP - P, xx = e % WP - P;
+        float v = 0.f;
+        if (xx >= 0 && xx < OW && yy >= 0 && yy < OH) v = dy[((pl0 + pl) * OH + yy) * OW + xx];
+        dyp[(pl0 + pl) * PP + e] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// epilogues: lane = position r (valid or not), half h, acc[a][reg] -> row m = 32a + (reg&3) + 8(reg>>2) + 4h
+// ---------------------------------------------------------------------------------------------------
+template <int SP>
+struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
+    float* y; const float* bias; int M; float scale; int relu;
+    template <int TM>
+    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM]) const {
+        const long off = (long)(r / SP) * M * SP + (r % SP);
+        const bool full = (M % 32 == 0);                  // wave-uniform: no per-row bound checks
+        const int m0 = 32 * TM * mg;
+        if (m0 >= M) return;
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            float bv[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) bv[g] = 0.f;
+            if (bias) {                                   // wave-uniform; all bias loads first, then the stores
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    bv[g] = bias[m < M ? m : M - 1];
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
+                float v = acc[a][g] * scale + bv[g];
+                if (relu) v = v > 0.f ? v : 0.f;
+                if (valid && (full || m < M)) y[off + (long)m * SP] = v;
+            }
+        }
+    }
+};
+
+template <int SP>
+struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
+    float* dx; const float* xact; int M;
+    template <int TM>
+    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM]) const {
+        const int m0 = 32 * TM * mg;
+        if (!valid || m0 >= M) return;
+        const long off = (long)(r / SP) * M * SP + (r % SP);
+        const bool full = (M % 32 == 0);
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            float gv[16];
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
+                gv[g] = xact ? xact[off + (long)(m < M ? m : M - 1) * SP] : 1.f;
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
+                const float v = gv[g] > 0.f ? acc[a][g] : 0.f;
+                if (full || m < M) dx[off + (long)m * SP] = v;
+            }
+        }
+    }
+};
+
+// stride-2 dgrad, CX == 32: M block = phase (py, px), one work item = the two px phases of row phase py = mg;
+// position r = (b, jy, jx) of the JH x JW phase grid; dX[b, cx, 2jy+py, 2jx + {0,1}] leaves as one 8-byte store
+template <int JH, int JW, int IH, int IW>
+struct SwPhase2Epi {
+    float* dx; const float* xact;
+    template <int TM>
+    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM]) const {
+        static_assert(TM == 2, "one work item = the two horizontal phases of one row phase");
+        static_assert(IH % 2 == 0 && IW % 2 == 0 && 2 * JH == IH && 2 * JW == IW, "even phase grid");
+        if (!valid) return;
+        constexpr int JP = JH * JW;
+        const int b = r / JP, j = r % JP;
+        const int jy = j / JW, jx = j % JW;
+        const long off = (long)b * 32 * (IH * IW) + (2 * jy + mg) * IW + 2 * jx;
+        f32x2 gt[16];
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int cx = (g & 3) + 8 * (g >> 2) + 4 * h;
+            gt[g] = xact ? *reinterpret_cast<const f32x2*>(xact + off + (long)cx * (IH * IW)) : f32x2{1.f, 1.f};
+        }
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            const int cx = (g & 3) + 8 * (g >> 2) + 4 * h;
+            f32x2 v;
+            v[0] = gt[g][0] > 0.f ? acc[0][g] : 0.f;
+            v[1] = gt[g][1] > 0.f ? acc[1][g] : 0.f;
+            *reinterpret_cast<f32x2*>(dx + off + (long)cx * (IH * IW)) = v;
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------------------
+// main kernel
+// ---------------------------------------------------------------------------------------------------
+template <class G, class Epi>
+__global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict__ x,
+                                                             const int64_t* __restrict__ idx,
+                                                             const float* __restrict__ wimg, const Epi epi, int R,
+                                                             int ntiles) {
+    using VT = typename TapVec<G::E>::type;
+    using VU = typename TapVec<G::E>::utype;
+    using AT = typename TapVec<G::EP>::type;
+    constexpr int TM = G::TM, TMW = G::TMW, MG = G::MG, NL = G::NL, NS = G::NS, C = G::CH;
+    extern __shared__ __attribute__((aligned(16))) float sw_smem[];
+
+    const int tid = threadIdx.x;
+    {   // resident weights: global image -> LDS (16-byte copies, 8 loads in flight per thread)
+        constexpr int n4 = (int)(G::image_floats() / 4);
+        const f32x4* src = reinterpret_cast<const f32x4*>(wimg);
+        f32x4* dst = reinterpret_cast<f32x4*>(sw_smem);
+        constexpr int UN = 8;
+        for (int i0 = tid; i0 < n4; i0 += UN * G::NT) {
+            f32x4 t[UN];
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { const int i = i0 + u * G::NT; t[u] = i < n4 ? src[i] : zero4(); }
+#pragma unroll
+            for (int u = 0; u < UN; ++u) { const int i = i0 + u * G::NT; if (i < n4) dst[i] = t[u]; }
+        }
+    }
+    __syncthreads();
+
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const float* lds_lane = sw_smem + (h * 32 + li) * G::EP;
+    constexpr long img_stride = (long)C * G::HW;
+    const int half_off = h * G::HOFF;
+
+    auto lane_base = [&](int tile, int& r, bool& valid) -> const float* {
+        r = tile * 32 + li;
+        valid = r < R;
+        const int rr = valid ? r : R - 1;
+        const int b = rr / G::SP, sp = rr % G::SP;
+        const int oy = sp / G::OW, ox = sp % G::OW;
+        const long img = idx ? (long)idx[b] : (long)b;
+        return x + img * img_stride + (oy * G::S) * G::W + ox * G::S + half_off;
+    };
+    auto stage_load = [&](VT (&buf)[NL], const float* base, int s) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) buf[i] = *reinterpret_cast<const VU*>(base + G::off0(s * NL + i));
+        __builtin_amdgcn_sched_barrier(0);     // the compiler otherwise sinks these loads below the MFMAs they overlap
+    };
+    // A fragments run through a 4-slot register ring, fetched from LDS two chunks ahead of their MFMAs (left to
+    // itself the compiler issues each ds_read right in front of its consumer and exposes the LDS latency)
+    constexpr int J = G::J;
+    AT ring[4][TMW];
+    auto load_a = [&](int q, int mg) {       // q: chunk pair index (compile time after unrolling), may run past J
+        const float* la = lds_lane + mg * (TMW * 64 * G::EP);
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+            ring[q & 3][a] = *reinterpret_cast<const AT*>(la + ((q % J) * TM + a) * 64 * G::EP);
+    };
+
+    // work items (tile, M group) are dealt round-robin over workgroups first, then waves: every CU gets the same
+    // number of items +-1 however few there are
+    const int nitems = ntiles * MG;
+    const int item_stride = gridDim.x * G::NWAVES;
+    int item = blockIdx.x + gridDim.x * wave;
+    if (item >= nitems) return;
+
+    VT buf[2][NL];
+    int r; bool valid;
+    int mg = item % MG;
+    const float* base = lane_base(item / MG, r, valid);
+    stage_load(buf[0], base, 0);
+    load_a(0, mg);
+    load_a(1, mg);
+
+    while (true) {
+        f32x16 acc[TMW];
+#pragma unroll
+        for (int a = 0; a < TMW; ++a)
+#pragma unroll
+            for (int g = 0; g < 16; ++g) acc[a][g] = 0.f;
+
+        const int next_item = item + item_stride;
+        const bool has_next = next_item < nitems;
+        int r_next = 0; bool valid_next = false;
+        const float* base_next = base;
+        const int mg_next = has_next ? next_item % MG : mg;
+        if (has_next) base_next = lane_base(next_item / MG, r_next, valid_next);
+
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            // the activations of stage s+1 (or of the next item's stage 0: it flies over the epilogue) are requested
+            // a whole stage of MFMAs before they are needed
+            // (unconditional: behind a branch the compiler can no longer count the loads in flight and drains them;
+            //  the last item simply re-requests its own first stage)
+            if (s + 1 < NS) stage_load(buf[(s + 1) & 1], base, s + 1);
+            else stage_load(buf[0], base_next, 0);
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                const int q = s * NL + i;
+                load_a(q + 2, q + 2 < J ? mg : mg_next);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < G::E; ++t)
+#pragma unroll
+                    for (int a = 0; a < TMW; ++a)
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[q & 3][a][t], buf[s & 1][i][t], acc[a], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        epi.template store<TMW>(r, valid, h, mg, acc);
+        if (!has_next) break;
+        item = next_item; base = base_next; r = r_next; valid = valid_next; mg = mg_next;
+    }
+}
+
+int sw_num_cus();
+
+template <class G, class Epi>
+int launch_conv_sw(const float* x, const int64_t* idx, const float* wimg, const Epi& epi, int R, hipStream_t stream) {
+    const int ntiles = cdiv(R, 32);
+    constexpr int smem_bytes = (int)G::lds_bytes();
+    auto kern = conv_sw_kernel<G, Epi>;
+    if (smem_bytes > 48 * 1024) {
+        static bool attr_set = false;      // per instantiation
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem_bytes);
+            if (e != hipSuccess) {
+                set_error("hipFuncSetAttribute(%d B LDS) failed: %s", smem_bytes, hipGetErrorString(e));
+                return (int)e;
+            }
+            attr_set = true;
+        }
+    }
+    int grid = cdiv((long)ntiles * G::MG, G::NWAVES);
+    const int cus = sw_num_cus();
+    if (grid > cus) grid = cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), smem_bytes, stream, x, idx, wimg, epi, R, ntiles);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+template <class G>
+int launch_sw_pack(const float* w, float* img, int M, int mode, int CX, int SD, hipStream_t stream) {
+    constexpr long n = G::image_floats();
+    hipLaunchKernelGGL((sw_pack_weights_kernel<G>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, w, img, M,
+                       mode, CX, SD);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace acktr

@@ -47,6 +47,62 @@ def check_summary(G, prefix, arr, tol, what=''):
         '%s %s rel err %g' % (what, prefix, err / max(scale, 1e-30))
 
 
+def cnn_gate_aware_grads(P, gates, x, old_logp, clip, c_e):
+    """fp64 PPO-minibatch gradients of the NatureCNN policy with the ReLU gates IMPOSED (`gates`: four boolean
+    arrays, the HIP path's own y1>0, y2>0, y3>0, feat>0), plus the fp64 pre-activations at the positions where an
+    imposed gate disagrees with the fp64 sign.
+
+    Why: a pre-activation whose fp64 magnitude lies below the fp32 accumulation noise (|pre| ~ 1e-7) has no
+    determined sign in fp32 -- the reference's own conv and ours may round it to different sides, and one
+    flipped gate moves the conv1 weight gradient by ~5e-4 relative.  Parity of the arithmetic is therefore
+    checked with the gates held fixed, and the disagreeing gates are required to be such undetermined ones."""
+    import torch.nn.functional as F
+    dd = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64)
+    W = OrderedDict((k, dd(v).requires_grad_(True)) for k, v in P.items())
+    g = [dd(np.asarray(m, np.float64)) for m in gates]
+    a = dd(x['obs']) / 255.0
+    flips = []
+    for li, (n, s) in enumerate((('base.main.0', 4), ('base.main.2', 2), ('base.main.4', 1))):
+        pre = F.conv2d(a, W[n + '.weight'], W[n + '.bias'], stride=s)
+        flips.append(pre.detach()[(pre.detach() > 0) != (g[li] > 0)].abs())
+        a = pre * g[li]
+    pre = a.reshape(a.shape[0], -1) @ W['base.main.7.weight'].t() + W['base.main.7.bias']
+    flips.append(pre.detach()[(pre.detach() > 0) != (g[3] > 0)].abs())
+    feat = pre * g[3]
+    values = feat @ W['base.critic_linear.weight'].t() + W['base.critic_linear.bias']
+    logits = feat @ W['dist.linear.weight'].t() + W['dist.linear.bias']
+    logsm = torch.log_softmax(logits, dim=-1)
+    act = torch.tensor(np.asarray(x['act']), dtype=torch.int64).view(-1, 1)
+    logp = logsm.gather(1, act)
+    ent = -(logsm.exp() * logsm).sum(-1).mean()
+    adv, vp, ret = dd(x['adv']), dd(x['vp']), dd(x['ret'])
+    ratio = torch.exp(logp - dd(old_logp).view(-1, 1))
+    action_loss = -torch.min(ratio * adv, torch.clamp(ratio, 1.0 - clip, 1.0 + clip) * adv).mean()
+    vpc = vp + (values - vp).clamp(-clip, clip)
+    value_loss = 0.5 * torch.max((values - ret).pow(2), (vpc - ret).pow(2)).mean()
+    (value_loss * 0.5 + action_loss - ent * c_e).backward()
+    return OrderedDict((k, v.grad.numpy()) for k, v in W.items()), torch.cat(flips).numpy()
+
+
+def check_cnn_grads(G, tag, P, gates, x, old_logp, clip, c_e, grads, tol):
+    """Gradient parity for a CNN case: the reference golden at `tol`; if that trips, the gate-aware fp64 check
+    (see cnn_gate_aware_grads) -- every disagreeing gate must be an undetermined one (|pre| < 1e-5) and there
+    may be at most a handful of them."""
+    try:
+        for n, g_ in grads.items():
+            check_summary(G, tag + '/grad/' + n, g_, tol, tag)
+        return 'golden'
+    except AssertionError:
+        pass
+    ref, flips = cnn_gate_aware_grads(P, gates, x, old_logp, clip, c_e)
+    assert flips.size <= 8 and (flips.size == 0 or float(flips.max()) < 1e-5), \
+        '%s: %d gates disagree with fp64, largest |pre| %g' % (tag, flips.size, float(flips.max()) if flips.size else 0)
+    for n, g_ in grads.items():
+        e = rel_err(g_, ref[n])
+        assert e <= tol, '%s %s gate-aware rel err %g' % (tag, n, e)
+    return 'gate-aware (%d undetermined gates)' % flips.size
+
+
 def eval_case_inputs(tag, kind, od, A, B, ci):
     """Inputs of golden group 'eval' (mirrors tests/golden/make_golden.py:g_eval)."""
     obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)

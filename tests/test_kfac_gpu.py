@@ -177,9 +177,13 @@ def test_acktr_update_vs_reference(ci):
         torch.manual_seed(555 + it)
         res = agent.update(rs)
         np.testing.assert_allclose(np.array(res), G[tag + '/update%d/losses' % it], rtol=1e-4, atol=1e-6)
+        # factor bar: 1e-4.  CNN: 5e-4, because a ReLU pre-activation below fp32 resolution (|pre| ~ 1e-7, about one
+        # per 10^6 activations, see helpers.cnn_gate_aware_grads) has no determined sign -- ours and the reference's
+        # conv may gate it differently, and one such gate moves a grad-output factor by ~2e-4 (measured: m_gg of conv2)
+        ftol = 1e-4 if kind == 'mlp' else 5e-4
         for i, m in enumerate(agent.optimizer.modules):
-            check_summary(G, tag + '/update%d/m_aa/%d' % (it, i), agent.optimizer.m_aa[m].cpu().numpy(), 1e-4, tag)
-            check_summary(G, tag + '/update%d/m_gg/%d' % (it, i), agent.optimizer.m_gg[m].cpu().numpy(), 1e-4, tag)
+            check_summary(G, tag + '/update%d/m_aa/%d' % (it, i), agent.optimizer.m_aa[m].cpu().numpy(), ftol, tag)
+            check_summary(G, tag + '/update%d/m_gg/%d' % (it, i), agent.optimizer.m_gg[m].cpu().numpy(), ftol, tag)
         e_ref, e_mine, e_mg = update_vector_errors(G, tag + '/update%d/kfgrad/' % it + '%s', names,
                                                    lambda n: params[n].grad.detach().cpu().numpy(),
                                                    lambda n: truth[it][unsplit_name(n)])

@@ -9,24 +9,6 @@
 namespace acktr {
 int pick_slices(long tiles, long K, long max_by_ws);
 
-// per-(oc, image slice) partial sums of dY [B, OC, SP] -> partial[slice*OC + oc]
-__global__ __launch_bounds__(256) void conv_bias_partial_kernel(const float* dy, int B, int OC, int SP,
-                                                                int imgs_per_slice, float* partial) {
-    __shared__ float sm[16];
-    const int oc = blockIdx.x;
-    const int b0 = blockIdx.y * imgs_per_slice;
-    int b1 = b0 + imgs_per_slice;
-    if (b1 > B) b1 = B;
-    const long n = (long)(b1 - b0) * SP;
-    float s = 0.f;
-    for (long i = threadIdx.x; i < n; i += 256) {
-        const int b = b0 + (int)(i / SP), sp = (int)(i % SP);
-        s += dy[((long)b * OC + oc) * SP + sp];
-    }
-    s = block_sum(s, sm);
-    if (threadIdx.x == 0) partial[(long)blockIdx.y * OC + oc] = s;
-}
-
 enum { GEOM_NONE = 0, GEOM_8S4 = 1, GEOM_4S2 = 2, GEOM_3S1 = 3 };
 static int geom_of(int H, int W, int KH, int KW, int S) {
     if (H == 84 && W == 84 && KH == 8 && KW == 8 && S == 4) return GEOM_8S4;
@@ -58,44 +40,37 @@ static int conv_fwd_pos_t(const float* x, const float* w, const float* bias, flo
     return launch_gemm<BM, 128, WM, WN>(wop, pop, epi, OC, RP, Kc, 1, s);
 }
 
-// dW[oc, kk] = scale * sum_r G(oc, r) * P(kk, r) with split-K over the position axis (R positions, padded or not)
+// dW[oc, kk] = scale * sum_r G(oc, r) * P(kk, r) with split-K over the position axis (R positions, padded or not).
+// db[oc] = sum_r G(oc, r) rides along as the GEMM's M-operand row sum (gemm_core.hpp): dY is read once.
+// Slab layout per K slice: [OC*Kc weights | OC (padded to 4) bias]; when db sits right behind dw (it does in the
+// policy's flat gradient buffer) one fixed-order reduction finishes both.
+static long wgrad_slab_floats(int OC, long Kc) { return (long)OC * Kc + (OC + 3) / 4 * 4; }
+
 template <int BM, int WM, int WN, class GOp, class POp>
-static int conv_wgrad_core(const GOp& gop, const POp& pop, const float* dy, float* dw, float* db, int B, int OC, int Kc,
-                           int R, int SP, float scale, float* ws, long ws_floats, hipStream_t s) {
-    const long bias_floats = db ? (long)64 * OC : 0;
+static int conv_wgrad_core(const GOp& gop, const POp& pop, float* dw, float* db, int OC, int Kc, int R, float scale,
+                           float* ws, long ws_floats, hipStream_t s) {
+    const long wk = (long)OC * Kc, slab = wgrad_slab_floats(OC, Kc);
     const long tiles = (long)cdiv(OC, BM) * cdiv(Kc, 128);
-    long max_by_ws = (ws_floats - bias_floats) / ((long)OC * Kc) - SLAB_GROUP_EXTRA;
+    long max_by_ws = ws_floats / slab - SLAB_GROUP_EXTRA;
     int ns = pick_slices(tiles, R, max_by_ws < 1 ? 1 : max_by_ws);
     if (ns > 1 && max_by_ws < ns) ns = 1;
-    int rc;
     if (ns == 1) {
         RowMajorEpi e = row_major_epi(dw, OC, Kc, Kc);
         e.scale = scale;
-        rc = launch_gemm<BM, 128, WM, WN>(gop, pop, e, OC, Kc, R, 1, s);
-        if (rc) return rc;
-    } else {
-        RowMajorEpi e = row_major_epi(ws, OC, Kc, Kc);
-        e.slab_stride = (long)OC * Kc;
-        rc = launch_gemm<BM, 128, WM, WN>(gop, pop, e, OC, Kc, R, ns, s);
-        if (rc) return rc;
-        rc = launch_slab_reduce(dw, ws, ns, (long)OC * Kc, (long)OC * Kc, scale, 0, s);
-        if (rc) return rc;
+        e.rowsum_dst = db;
+        return launch_gemm<BM, 128, WM, WN>(gop, pop, e, OC, Kc, R, 1, s);
     }
-    if (db) {
-        if (ws_floats < bias_floats + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OC * Kc : 0)) {
-            set_error("conv2d_wgrad: workspace too small for bias partials");
-            return -1;
-        }
-        float* part = ws + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OC * Kc : 0);
-        int nsl = B < 64 ? B : 64;
-        const int ips = cdiv(B, nsl);
-        nsl = cdiv(B, ips);
-        hipLaunchKernelGGL(conv_bias_partial_kernel, dim3(OC, nsl), dim3(256), 0, s, dy, B, OC, SP, ips, part);
-        ACKTR_LAUNCH_CHECK();
-        rc = launch_slab_reduce(db, part, nsl, OC, OC, 1.f, 0, s);
-        if (rc) return rc;
-    }
-    return 0;
+    RowMajorEpi e = row_major_epi(ws, OC, Kc, Kc);
+    e.slab_stride = slab;
+    e.scale = scale;                      // per-slab scaling keeps one reduction for weights and (unscaled) bias
+    e.rowsum_dst = db ? ws + wk : nullptr;
+    e.rowsum_stride = slab;
+    int rc = launch_gemm<BM, 128, WM, WN>(gop, pop, e, OC, Kc, R, ns, s);
+    if (rc) return rc;
+    if (db == dw + wk && OC % 4 == 0) return launch_slab_reduce(dw, ws, ns, wk + OC, slab, 1.f, 0, s);
+    rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
+    if (rc || !db) return rc;
+    return launch_slab_reduce(db, ws + wk, ns, OC, slab, 1.f, 0, s);
 }
 
 template <int KH, int KW, int S, int H, int W, int BM, int WM, int WN>
@@ -106,7 +81,7 @@ static int conv_wgrad_t(const float* x, const int64_t* idx, const float* dy, flo
     const int Kc = C * KH * KW, R = B * SP;
     ConvOutKC<SP> gop{dy, OC, R};
     Patch pop{x, idx, C, (long)C * H * W, R, Kc};
-    return conv_wgrad_core<BM, WM, WN>(gop, pop, dy, dw, db, B, OC, Kc, R, SP, scale, ws, ws_floats, s);
+    return conv_wgrad_core<BM, WM, WN>(gop, pop, dw, db, OC, Kc, R, scale, ws, ws_floats, s);
 }
 
 // stride-1 layers without a gather: both operands stream 4 padded positions per 16-byte load
@@ -117,8 +92,7 @@ static int conv_wgrad_pos_t(const float* x, const float* dy, float* dw, float* d
     const int Kc = C * KH * KW, RP = B * Patch::PP;
     ConvOutPos<Patch::OH, Patch::OW, OWP> gop{dy, dy + (long)B * OC * Patch::OH * Patch::OW, OC, RP};
     Patch pop{x, x + (long)B * C * H * W, C, RP, Kc};
-    return conv_wgrad_core<BM, WM, WN>(gop, pop, dy, dw, db, B, OC, Kc, RP, Patch::OH * Patch::OW, scale, ws, ws_floats,
-                                       s);
+    return conv_wgrad_core<BM, WM, WN>(gop, pop, dw, db, OC, Kc, RP, scale, ws, ws_floats, s);
 }
 
 // dgrad weights re-packed once per call into dense per-phase matrices Wp[phase][c][k], k = (oc, a, a'), rows padded
@@ -280,7 +254,7 @@ extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, i
     const int BM = OC <= 32 ? 32 : 64;
     const int OWP = (OW + 3) / 4 * 4;      // the stride-1 path reduces over padded positions
     const int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OWP, 1024);
-    return ((long)(ns + SLAB_GROUP_EXTRA) * OC * Kc + (long)64 * OC) * (long)sizeof(float);
+    return (long)(ns + SLAB_GROUP_EXTRA) * wgrad_slab_floats(OC, Kc) * (long)sizeof(float);
 }
 
 extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw,

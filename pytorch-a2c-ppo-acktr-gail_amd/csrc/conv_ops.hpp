@@ -84,6 +84,7 @@ struct ConvOutKC {
 // forward epilogue: (m = oc, n = r) -> Y[b, oc, sp] = relu?(acc*scale + bias[oc])
 template <int SP>
 struct ConvFwdEpi {
+    static constexpr bool HAS_ROWSUM = false;
     float* y; const float* bias; int OC; int R; float scale; int relu;
     struct Col { long off; int ok; };
     __device__ __forceinline__ Col col(int n) const {
@@ -163,6 +164,7 @@ struct DgradDy {   // N-operand: rows = input positions of one phase, k = (oc, a
 
 template <int KH, int KW, int S, int OH, int OW>
 struct DgradEpi {  // (m = c, n = pos) -> dX[b, c, iy, ix] = acc * (X[b,c,iy,ix] > 0 if relu_gate)
+    static constexpr bool HAS_ROWSUM = false;
     using G = DgradGeom<KH, KW, S, OH, OW>;
     float* dx; const float* xact; int C; int NP;
     struct Col { long off; int ok; };
@@ -248,6 +250,7 @@ struct ConvOutPos {
 
 template <int OH, int OW, int OWP>
 struct ConvFwdEpiPos {   // (m = oc, n = padded position) -> Y[b, oc, oy, ox]
+    static constexpr bool HAS_ROWSUM = false;
     static constexpr int SP = OH * OW, PP = OH * OWP;
     float* y; const float* bias; int OC; int RP; float scale; int relu;
     struct Col { long off; int ok; };

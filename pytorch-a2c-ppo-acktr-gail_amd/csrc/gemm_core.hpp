@@ -102,6 +102,9 @@ struct OperandTile {
 // Epilogue concept:
 //   struct Col;  Col col(int n) const;                       // per-lane column state (validity, offsets)
 //   void st(const Col&, int m, float acc, int kslice) const; // bounds-checks m itself
+//   static constexpr bool HAS_ROWSUM;  bool wants_rowsum() const;  void rowsum(int m, float v, int kslice) const;
+//     optional: sum over k of the M operand's rows (the bias gradient of a wgrad GEMM, where the M operand is dY),
+//     accumulated from the registers the loader holds anyway -- dY is not read a second time for it
 // ------------------------------------------------------------------------------------------
 template <int BM, int BN, int WM, int WN, class MOp, class NOp, class Epi, bool ZBATCH = false>
 __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const NOp nop, const Epi epi, int K,
@@ -137,9 +140,24 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
     mt.init(mop, m0, tid);
     nt.init(nop, n0, tid);
 
+    bool do_rowsum = false;
+    if constexpr (Epi::HAS_ROWSUM) do_rowsum = epi.wants_rowsum() && blockIdx.x == 0;     // workgroup-uniform
+    f32x4 rs[MT::UNITS];
+#pragma unroll
+    for (int u = 0; u < MT::UNITS; ++u) rs[u] = zero4();
+    auto rowsum_add = [&]() {
+        if constexpr (Epi::HAS_ROWSUM) {
+            if (do_rowsum) {
+#pragma unroll
+                for (int u = 0; u < MT::UNITS; ++u) rs[u] += mt.regs[u];
+            }
+        }
+    };
+
     if (nk > 0) {
         mt.load(mop, m0, kbeg, tid);
         nt.load(nop, n0, kbeg, tid);
+        rowsum_add();
         mt.store(smem, tid);
         nt.store(smem + MT::SMEM, tid);
     }
@@ -152,6 +170,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
         if (more) {
             mt.load(mop, m0, kbeg + (kt + 1) * GK, tid);
             nt.load(nop, n0, kbeg + (kt + 1) * GK, tid);
+            rowsum_add();
         }
 #pragma unroll
         for (int q = 0; q < GK / 8; ++q) {
@@ -175,6 +194,34 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
             nt.store(dM + MT::SMEM, tid);
         }
         __syncthreads();
+    }
+
+    if constexpr (Epi::HAS_ROWSUM) {
+        if (do_rowsum) {
+            if constexpr (MOp::INNER_IS_K) {     // thread holds 4 k of row (tid>>3)+32u; the row's 8 threads are adjacent lanes
+#pragma unroll
+                for (int u = 0; u < MT::UNITS; ++u) {
+                    float v = (rs[u][0] + rs[u][1]) + (rs[u][2] + rs[u][3]);
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    if ((tid & 7) == 0) epi.rowsum(m0 + (tid >> 3) + 32 * u, v, (int)blockIdx.z);
+                }
+            } else {                             // thread holds rows 4((tid&7)+8u)..+3 at k = tid>>3: reduce over k through LDS
+                float* red = smem;               // the main loop ended on a barrier: LDS is free
+#pragma unroll
+                for (int u = 0; u < MT::UNITS; ++u)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) red[(tid >> 3) * BM + 4 * ((tid & 7) + 8 * u) + j] = rs[u][j];
+                __syncthreads();
+                if (tid < BM) {
+                    float v = 0.f;
+#pragma unroll 8
+                    for (int k = 0; k < 32; ++k) v += red[k * BM + tid];
+                    epi.rowsum(m0 + tid, v, (int)blockIdx.z);
+                }
+            }
+        }
     }
 
     // epilogue: lane -> column n, registers -> rows m
@@ -301,6 +348,12 @@ struct RowMajorEpi {
     const float* bias_n; const float* bias_m; float scale; int act;
     const float* gate_src; long ldg; int gate; int accumulate;
     const float* div_m; const float* div_n; float div_add;     // v /= (div_m[m]*div_n[n] + div_add)  (KFAC damping)
+    float* rowsum_dst; long rowsum_stride;                     // optional: rowsum_dst[slab*stride + m] = sum_k Mop(m, k)
+    static constexpr bool HAS_ROWSUM = true;
+    __device__ __forceinline__ bool wants_rowsum() const { return rowsum_dst != nullptr; }
+    __device__ __forceinline__ void rowsum(int m, float v, int ks) const {
+        if (m < M) rowsum_dst[(long)ks * rowsum_stride + m] = v;
+    }
     struct Col { int n; int ok; float bn; float dn; };
     __device__ __forceinline__ Col col(int n) const {
         Col cc; cc.n = n; cc.ok = n < N; cc.bn = (cc.ok && bias_n) ? bias_n[n] : 0.f;
@@ -323,7 +376,7 @@ struct RowMajorEpi {
 static inline RowMajorEpi row_major_epi(float* c, int M, int N, long ldc) {
     RowMajorEpi e; e.c = c; e.M = M; e.N = N; e.ldc = ldc; e.slab_stride = 0; e.bias_n = nullptr; e.bias_m = nullptr;
     e.scale = 1.f; e.act = 0; e.gate_src = nullptr; e.ldg = 0; e.gate = 0; e.accumulate = 0;
-    e.div_m = nullptr; e.div_n = nullptr; e.div_add = 0.f; return e;
+    e.div_m = nullptr; e.div_n = nullptr; e.div_add = 0.f; e.rowsum_dst = nullptr; e.rowsum_stride = 0; return e;
 }
 
 // Fixed-order slab reduction: dst[i] (=|+=) scale * sum_s slabs[s*stride + i].  With >= 16 slabs it runs in two

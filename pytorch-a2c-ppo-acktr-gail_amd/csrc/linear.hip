@@ -99,19 +99,6 @@ int launch_slab_reduce(float* dst, const float* slabs, int nslabs, long n, long 
     return 0;
 }
 
-// column sums of a row-major [rows, cols] matrix over a row slice -> partial[slice*cols + col]
-__global__ __launch_bounds__(256) void col_sum_partial_kernel(const float* a, int rows, int cols, int rows_per_slice,
-                                                              float* partial) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
-    const int r0 = blockIdx.y * rows_per_slice;
-    int r1 = r0 + rows_per_slice;
-    if (r1 > rows) r1 = rows;
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += a[(long)r * cols + c];
-    partial[(long)blockIdx.y * cols + c] = s;
-}
-
 // Tile choice: 128x128 when it alone fills the chip, else 64x128 (twice the workgroups), skinny shapes get
 // 128x32 / 32x128.  256 CUs want a few hundred workgroups; split-K supplies the rest (see pick_slices).
 static int tile_rows_for(int M, int N) {
@@ -184,6 +171,142 @@ static int fwd_slices(int B, int IN, int OUT, long ws_floats) {
     return n < 2 ? 1 : (int)n;
 }
 
+// ==========================================================================================
+// Skinny layers (OUT <= 8: the fused critic+actor head [1+A, hidden], the MLP critic head).  A 32x32 MFMA tile
+// would be 3/4 padding and the launch is latency-bound, so these run on the vector ALUs, streaming each
+// activation once with 16-byte loads.  Requirements: IN % 4 == 0, 16-byte aligned rows (else the tile GEMM runs).
+// ==========================================================================================
+constexpr int SK_MAX_OUT = 8;
+static bool skinny_ok(const void* a, const void* b, const void* c, int IN, int OUT) {
+    return OUT <= SK_MAX_OUT && IN % 4 == 0 && IN >= 4 &&
+           ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)c)) & 15) == 0;
+}
+
+// y[b, o] = act(sum_i x[b,i] w[o,i] + bias[o]); one wave per row, lanes stride the reduction in float4s
+__global__ __launch_bounds__(256) void skinny_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
+                                                         int IN, int OUT, int act) {
+    constexpr int RW = 1;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.x * 4 + wave) * RW;
+    if (r0 >= B) return;
+    float acc[RW][SK_MAX_OUT];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int o = 0; o < SK_MAX_OUT; ++o) acc[r][o] = 0.f;
+    for (int k = lane * 4; k < IN; k += 256) {
+        f32x4 xv[RW];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int rr = r0 + r < B ? r0 + r : B - 1;
+            xv[r] = *reinterpret_cast<const f32x4*>(x + (long)rr * IN + k);
+        }
+#pragma unroll
+        for (int o = 0; o < SK_MAX_OUT; ++o) {
+            if (o < OUT) {
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)o * IN + k);
+#pragma unroll
+                for (int r = 0; r < RW; ++r)
+                    acc[r][o] += xv[r][0] * wv[0] + xv[r][1] * wv[1] + xv[r][2] * wv[2] + xv[r][3] * wv[3];
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int o = 0; o < SK_MAX_OUT; ++o) {
+            if (o < OUT) {                                   // wave-uniform
+                float v = wave_sum(acc[r][o]);
+                if (lane == 0 && r0 + r < B) {
+                    v += bias ? bias[o] : 0.f;
+                    if (act == 1) v = v > 0.f ? v : 0.f;
+                    else if (act == 2) v = tanhf(v);
+                    y[(long)(r0 + r) * OUT + o] = v;
+                }
+            }
+        }
+}
+
+// dx[b, i..i+3] (=|+=) (sum_o dy[b,o] w[o,i..i+3]) * gate
+__global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           const float* __restrict__ gate_src, int gate,
+                                                           float* __restrict__ dx, int B, int IN, int OUT,
+                                                           int accumulate) {
+    const int q = IN / 4;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)B * q) return;
+    const int b = (int)(t / q), i = (int)(t % q) * 4;
+    f32x4 a = zero4();
+#pragma unroll
+    for (int o = 0; o < SK_MAX_OUT; ++o) {
+        if (o < OUT) {
+            const float d = dy[(long)b * OUT + o];
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(w + (long)o * IN + i);
+            a += d * wv;
+        }
+    }
+    const long off = (long)b * IN + i;
+    if (gate) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(gate_src + off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) a[j] = gate == 1 ? (h[j] > 0.f ? a[j] : 0.f) : a[j] * (1.f - h[j] * h[j]);
+    }
+    if (accumulate) a += *reinterpret_cast<const f32x4*>(dx + off);
+    *reinterpret_cast<f32x4*>(dx + off) = a;
+}
+
+// per row slice: pw[slice][o][i] = sum_{b in slice} dy[b,o] x[b,i];  pb[slice][o] = sum_b dy[b,o]
+__global__ __launch_bounds__(128) void skinny_wgrad_partial_kernel(const float* __restrict__ dy,
+                                                                  const float* __restrict__ x, float* __restrict__ pw,
+                                                                  float* __restrict__ pb, int B, int IN, int OUT,
+                                                                  int rows_per_slice) {
+    const int c4 = (blockIdx.x * 128 + threadIdx.x) * 4;
+    const int r0 = blockIdx.y * rows_per_slice;
+    int r1 = r0 + rows_per_slice;
+    if (r1 > B) r1 = B;
+    if (pb && blockIdx.x == 0 && threadIdx.x < OUT) {
+        float sb = 0.f;
+        for (int r = r0; r < r1; ++r) sb += dy[(long)r * OUT + threadIdx.x];
+        pb[(long)blockIdx.y * OUT + threadIdx.x] = sb;
+    }
+    if (c4 >= IN) return;
+    f32x4 acc[SK_MAX_OUT];
+#pragma unroll
+    for (int o = 0; o < SK_MAX_OUT; ++o) acc[o] = zero4();
+    for (int r = r0; r < r1; ++r) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)r * IN + c4);
+#pragma unroll
+        for (int o = 0; o < SK_MAX_OUT; ++o)
+            if (o < OUT) acc[o] += dy[(long)r * OUT + o] * xv;          // dy: wave-uniform address
+    }
+#pragma unroll
+    for (int o = 0; o < SK_MAX_OUT; ++o)
+        if (o < OUT) *reinterpret_cast<f32x4*>(pw + ((long)blockIdx.y * OUT + o) * IN + c4) = acc[o];
+}
+// db[o] = sum over slices of pb[slice][o], fixed order: thread (g, o) sums slices g, g+32, ..., then the 32 groups in order
+__global__ __launch_bounds__(256) void skinny_bias_reduce_kernel(const float* __restrict__ pb, int nsl, int OUT,
+                                                                 float* __restrict__ db) {
+    __shared__ float sm[32][SK_MAX_OUT];
+    const int o = threadIdx.x & 7, g = threadIdx.x >> 3;
+    float v = 0.f;
+    if (o < OUT)
+        for (int k = g; k < nsl; k += 32) v += pb[(long)k * OUT + o];
+    sm[g][o] = v;
+    __syncthreads();
+    if (threadIdx.x < OUT) {
+        float t = 0.f;
+        for (int k = 0; k < 32; ++k) t += sm[k][threadIdx.x];
+        db[threadIdx.x] = t;
+    }
+}
+static int skinny_slices(int B) {
+    int n = B / 8;
+    if (n < 1) n = 1;
+    if (n > 128) n = 128;
+    return n;
+}
+
 extern "C" long acktr_linear_fwd_workspace_bytes(int B, int IN, int OUT) {
     const int ns = fwd_slices(B, IN, OUT, 1L << 40);
     return ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * B * OUT * (long)sizeof(float) : 0;
@@ -195,6 +318,11 @@ extern "C" int acktr_linear_fwd_f32(const float* x, const float* w, const float*
     ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_fwd: bad sizes B=%d IN=%d OUT=%d", B, IN, OUT);
     ACKTR_ARG(act >= 0 && act <= 2, "linear_fwd: act must be 0 (none), 1 (relu) or 2 (tanh)");
     hipStream_t s = (hipStream_t)stream;
+    if (skinny_ok(x, w, x, IN, OUT)) {
+        hipLaunchKernelGGL(skinny_fwd_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, x, w, bias, y, B, IN, OUT, act);
+        ACKTR_LAUNCH_CHECK();
+        return 0;
+    }
     float* ws = (float*)workspace;
     const int ns = (ws && (((uintptr_t)ws | (uintptr_t)y) & 15) == 0)
                        ? fwd_slices(B, IN, OUT, workspace_bytes / (long)sizeof(float)) : 1;
@@ -216,6 +344,12 @@ extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const flo
     ACKTR_ARG(dy && w && dx, "linear_dgrad: null pointer");
     ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_dgrad: bad sizes");
     ACKTR_ARG(gate >= 0 && gate <= 2 && (gate == 0 || gate_src), "linear_dgrad: gate needs gate_src");
+    if (skinny_ok(w, dx, gate_src, IN, OUT)) {
+        hipLaunchKernelGGL(skinny_dgrad_kernel, dim3(cdiv((long)B * (IN / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                           dy, w, gate_src, gate, dx, B, IN, OUT, accumulate);
+        ACKTR_LAUNCH_CHECK();
+        return 0;
+    }
     RowMajorEpi e = row_major_epi(dx, B, IN, IN);
     e.gate = gate; e.gate_src = gate_src; e.ldg = IN; e.accumulate = accumulate;
     // dX[b, i] = sum_o dY[b, o] * W[o, i]   : A = dY (k contiguous), B(n=i, k=o) = W[o*IN + i] (row contiguous)
@@ -223,9 +357,13 @@ extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const flo
 }
 
 extern "C" long acktr_linear_wgrad_workspace_bytes(int B, int IN, int OUT) {
+    if (OUT <= SK_MAX_OUT && IN % 4 == 0) {
+        const long nsl = skinny_slices(B) + SLAB_GROUP_EXTRA;
+        return (nsl * OUT * IN + nsl * OUT + 4) * (long)sizeof(float);
+    }
     const long tiles = gemm_tiles(OUT, IN);
     const int ns = pick_slices(tiles, B, 1024);
-    return ((long)(ns + SLAB_GROUP_EXTRA) * OUT * IN + (long)64 * OUT) * (long)sizeof(float);
+    return (long)(ns + SLAB_GROUP_EXTRA) * ((long)OUT * IN + (OUT + 3) / 4 * 4) * (long)sizeof(float);
 }
 
 extern "C" int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT,
@@ -235,39 +373,48 @@ extern "C" int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     const long ws_floats = workspace ? workspace_bytes / (long)sizeof(float) : 0;
-    const long bias_floats = db ? (long)64 * OUT : 0;
+    if (skinny_ok(x, dw, ws, IN, OUT)) {
+        const int nsl0 = skinny_slices(B);
+        const int rps = cdiv(B, nsl0);
+        const int nsl = cdiv(B, rps);
+        const long wpart = (long)(nsl + SLAB_GROUP_EXTRA) * OUT * IN;
+        const long need = wpart + (long)(nsl + SLAB_GROUP_EXTRA) * OUT;
+        if (ws && ws_floats >= need) {
+            float* pb = db ? ws + wpart : nullptr;
+            hipLaunchKernelGGL(skinny_wgrad_partial_kernel, dim3(cdiv(IN / 4, 128), nsl), dim3(128), 0, s, dy, x, ws, pb,
+                               B, IN, OUT, rps);
+            ACKTR_LAUNCH_CHECK();
+            int rc = launch_slab_reduce(dw, ws, nsl, (long)OUT * IN, (long)OUT * IN, 1.f, 0, s);
+            if (rc) return rc;
+            if (db) {
+                hipLaunchKernelGGL(skinny_bias_reduce_kernel, dim3(1), dim3(256), 0, s, pb, nsl, OUT, db);
+                ACKTR_LAUNCH_CHECK();
+            }
+            return 0;
+        }
+    }
+    // dW[o, i] = sum_b dY[b, o] * X[b, i] : A(m=o, k=b) = dy[b*OUT + o], B(n=i, k=b) = x[b*IN + i];
+    // db[o] = sum_b dY[b, o] is the GEMM's M-operand row sum.  Slab layout [OUT*IN | OUT padded to 4] per K slice.
+    const long wk = (long)OUT * IN, slab = wk + (OUT + 3) / 4 * 4;
     const long tiles = gemm_tiles(OUT, IN);
-    long max_by_ws = (ws_floats - bias_floats) / ((long)OUT * IN) - SLAB_GROUP_EXTRA;
+    long max_by_ws = ws_floats / slab - SLAB_GROUP_EXTRA;
     int ns = pick_slices(tiles, B, max_by_ws < 1 ? 1 : max_by_ws);
     if (ns > 1 && max_by_ws < ns) ns = 1;
-    // dW[o, i] = sum_b dY[b, o] * X[b, i] : A(m=o, k=b) = dy[b*OUT + o], B(n=i, k=b) = x[b*IN + i]
-    int rc;
     if (ns == 1) {
         RowMajorEpi e = row_major_epi(dw, OUT, IN, IN);
-        rc = gemm_rowmajor(dy, 1, OUT, x, 1, IN, e, OUT, IN, B, 1, s);
-        if (rc) return rc;
-    } else {
-        RowMajorEpi e = row_major_epi(ws, OUT, IN, IN);
-        e.slab_stride = (long)OUT * IN;
-        rc = gemm_rowmajor(dy, 1, OUT, x, 1, IN, e, OUT, IN, B, ns, s);
-        if (rc) return rc;
-        rc = launch_slab_reduce(dw, ws, ns, (long)OUT * IN, (long)OUT * IN, 1.f, 0, s);
-        if (rc) return rc;
+        e.rowsum_dst = db;
+        return gemm_rowmajor(dy, 1, OUT, x, 1, IN, e, OUT, IN, B, 1, s);
     }
-    if (db) {
-        ACKTR_ARG(ws_floats >= bias_floats + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OUT * IN : 0),
-                  "linear_wgrad: workspace too small for the bias partials (%ld floats)", ws_floats);
-        float* part = ws + (ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * OUT * IN : 0);
-        int nsl = cdiv(B, 64);
-        if (nsl > 64) nsl = 64;
-        const int rps = cdiv(B, nsl);
-        nsl = cdiv(B, rps);
-        hipLaunchKernelGGL(col_sum_partial_kernel, dim3(cdiv(OUT, 256), nsl), dim3(256), 0, s, dy, B, OUT, rps, part);
-        ACKTR_LAUNCH_CHECK();
-        rc = launch_slab_reduce(db, part, nsl, OUT, OUT, 1.f, 0, s);
-        if (rc) return rc;
-    }
-    return 0;
+    RowMajorEpi e = row_major_epi(ws, OUT, IN, IN);
+    e.slab_stride = slab;
+    e.rowsum_dst = db ? ws + wk : nullptr;
+    e.rowsum_stride = slab;
+    int rc = gemm_rowmajor(dy, 1, OUT, x, 1, IN, e, OUT, IN, B, ns, s);
+    if (rc) return rc;
+    if (db == dw + wk && OUT % 4 == 0 && wk % 4 == 0) return launch_slab_reduce(dw, ws, ns, wk + OUT, slab, 1.f, 0, s);
+    rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
+    if (rc || !db) return rc;
+    return launch_slab_reduce(db, ws + wk, ns, OUT, slab, 1.f, 0, s);
 }
 
 /* Generic strided fp32 GEMM: C[M,N] = alpha * A(m,k) B(n,k) (+ beta*C), used by the KFAC preconditioner.

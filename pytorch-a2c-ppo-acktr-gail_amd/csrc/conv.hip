@@ -22,9 +22,13 @@ static int conv_fwd_t(const float* x, const int64_t* idx, const float* w, const 
                       int OC, float scale, int relu, hipStream_t s) {
     using Patch = Im2col<KH, KW, S, H, W, true>;
     const int Kc = C * KH * KW, R = B * Patch::SP;
-    DenseKC wop{w, OC, Kc, (long)Kc, vec_ok(w, Kc)};
     Patch pop{x, idx, C, (long)C * H * W, R, Kc};
     ConvFwdEpi<Patch::SP> epi{y, bias, OC, R, scale, relu};
+    if (vec_ok(w, Kc)) {
+        DenseKCT<true> wop{w, OC, Kc, (long)Kc};
+        return launch_gemm<BM, 128, WM, WN>(wop, pop, epi, OC, R, Kc, 1, s);
+    }
+    DenseKCT<false> wop{w, OC, Kc, (long)Kc};
     return launch_gemm<BM, 128, WM, WN>(wop, pop, epi, OC, R, Kc, 1, s);
 }
 
@@ -34,9 +38,13 @@ static int conv_fwd_pos_t(const float* x, const float* w, const float* bias, flo
                           float scale, int relu, hipStream_t s) {
     using Patch = Im2colPos<KH, KW, H, W, OWP, false>;
     const int Kc = C * KH * KW, RP = B * Patch::PP;
-    DenseKC wop{w, OC, Kc, (long)Kc, vec_ok(w, Kc)};
     Patch pop{x, x + (long)B * C * H * W, C, RP, Kc};
     ConvFwdEpiPos<Patch::OH, Patch::OW, OWP> epi{y, bias, OC, RP, scale, relu};
+    if (vec_ok(w, Kc)) {
+        DenseKCT<true> wop{w, OC, Kc, (long)Kc};
+        return launch_gemm<BM, 128, WM, WN>(wop, pop, epi, OC, RP, Kc, 1, s);
+    }
+    DenseKCT<false> wop{w, OC, Kc, (long)Kc};
     return launch_gemm<BM, 128, WM, WN>(wop, pop, epi, OC, RP, Kc, 1, s);
 }
 
@@ -78,7 +86,7 @@ static int conv_wgrad_t(const float* x, const int64_t* idx, const float* dy, flo
                         int OC, float scale, float* ws, long ws_floats, hipStream_t s) {
     using Patch = Im2col<KH, KW, S, H, W, false>;
     constexpr int SP = Patch::SP;
-    const int Kc = C * KH * KW, R = B * SP;
+    const int Kc = C * KH * KW, R = B * Patch::SPP;      // reduction over positions, each image padded to SPP
     ConvOutKC<SP> gop{dy, OC, R};
     Patch pop{x, idx, C, (long)C * H * W, R, Kc};
     return conv_wgrad_core<BM, WM, WN>(gop, pop, dw, db, OC, Kc, R, scale, ws, ws_floats, s);
@@ -121,9 +129,14 @@ struct DgradWPacked {   // M-operand: rows = input channel c of phase blockIdx.z
     __device__ __forceinline__ Outer prep(int c) const {
         Outer o; o.ok = c < C; o.rp = wp + ((long)blockIdx.z * C + (o.ok ? c : 0)) * Kredp; return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int k0) const {
-        if (!o.ok || k0 >= Kredp) return zero4();
-        return *reinterpret_cast<const f32x4*>(o.rp + k0);
+    __device__ static __forceinline__ f32x4 post(const f32x4& v, int meta) { return sel4(meta & 1, v); }
+    struct Inner { int k0; };
+    __device__ __forceinline__ Inner prep_inner(int k0) const { return Inner{k0}; }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        const int k0 = in.k0;
+        const bool ok = o.ok && k0 < Kredp;
+        meta = ok;
+        return *reinterpret_cast<const f32x4*>(o.rp + (ok ? k0 : 0));
     }
 };
 

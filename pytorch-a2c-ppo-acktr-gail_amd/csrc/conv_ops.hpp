@@ -19,29 +19,43 @@ template <int KH, int KW, int S, int H, int W, bool INNER_K>
 struct Im2col {
     static constexpr bool INNER_IS_K = INNER_K;
     static constexpr int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1, SP = OH * OW, KK = KH * KW, HW = H * W;
-    const float* x; const int64_t* idx; int C; long img_stride; int R; int Kc;
+    // wgrad (INNER_K = false): the reduction runs over positions with each image padded to SPP = roundup(SP, 4)
+    // (positions sp >= SP contribute zeros), so that the dY operand can fetch 4 positions of one image per load
+    static constexpr int SPP = INNER_K ? SP : (SP + 3) / 4 * 4;
+    const float* x; const int64_t* idx; int C; long img_stride; int R; int Kc;     // R counts (padded) positions
     struct Outer { const float* p; int ok; };
     __device__ __forceinline__ Outer prep(int r) const {
-        Outer o; o.ok = r < R;
-        const int rr = o.ok ? r : 0;
-        const int b = rr / SP, sp = rr % SP;
-        const int oy = sp / OW, ox = sp % OW;
+        Outer o;
+        const bool in = r < R;
+        const int rr = in ? r : 0;
+        const int b = rr / SPP, sp = rr % SPP;
+        o.ok = in && sp < SP;
+        const int spc = sp < SP ? sp : 0;
+        const int oy = spc / OW, ox = spc % OW;
         const long img = idx ? (long)idx[b] : (long)b;
         o.p = x + img * img_stride + (oy * S) * W + ox * S;
         return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int kk0) const {
-        f32x4 v = zero4();
-        if (!o.ok || kk0 >= Kc) return v;
-        if constexpr (KW % 4 == 0) {          // 4 taps share (c, ky): contiguous in x   (Kc % 4 == 0)
-            const int c = kk0 / KK, rem = kk0 % KK;
-            const float* q = o.p + c * HW + (rem / KW) * W + (rem % KW);
-            if constexpr (S % 4 == 0 && W % 4 == 0) {
-                return *reinterpret_cast<const f32x4*>(q);
-            } else {                          // the 4 taps lie inside the image row: one unaligned 16-byte load
-                return *reinterpret_cast<const f32x4_u*>(q);
-            }
+    __device__ static __forceinline__ f32x4 post(const f32x4& v, int meta) { return sel4(meta & 1, v); }
+    struct Inner { int kk0; int off; int ok; };     // patch index -> offset inside the window (K-invariant for wgrad)
+    __device__ __forceinline__ Inner prep_inner(int kk0) const {
+        Inner in; in.kk0 = kk0; in.ok = kk0 < Kc;
+        const int kc = in.ok ? kk0 : 0;
+        const int c = kc / KK, rem = kc % KK;
+        in.off = c * HW + (rem / KW) * W + (rem % KW);
+        return in;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        const int kk0 = in.kk0;
+        if constexpr (KW % 4 == 0) {          // 4 taps share (c, ky): contiguous in x   (Kc % 4 == 0); branch-free
+            meta = o.ok && in.ok;
+            const float* q = o.p + in.off;
+            if constexpr (S % 4 == 0 && W % 4 == 0) return *reinterpret_cast<const f32x4*>(q);
+            else return *reinterpret_cast<const f32x4_u*>(q);          // inside the image row: unaligned 16 bytes
         } else {
+            meta = 1;
+            f32x4 v = zero4();
+            if (!o.ok || kk0 >= Kc) return v;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int kk = kk0 + j;
@@ -55,28 +69,43 @@ struct Im2col {
     }
 };
 
-// Y / dY [B, OC, SP] viewed as (oc, r = (b, sp));  k-contiguous M-operand of wgrad
+// Y / dY [B, OC, SP] viewed as (oc, k = (b, sp')) with sp' running to SPP = roundup(SP, 4): k-contiguous M-operand
+// of wgrad.  A group of 4 k never crosses an image; the last group of an image holds SP % 4 real positions and is
+// fetched from the image's last 4 floats and shifted down, so no load ever leaves the tensor.  Branch-free.
 template <int SP>
 struct ConvOutKC {
     static constexpr bool INNER_IS_K = true;
-    const float* p; int OC; int R;
+    static constexpr int SPP = (SP + 3) / 4 * 4, TAIL = SP % 4;      // TAIL real positions in a partial last group
+    const float* p; int OC; int R;                                   // R = B * SPP
     struct Outer { const float* cp; int ok; };
     __device__ __forceinline__ Outer prep(int oc) const {
         Outer o; o.ok = oc < OC; o.cp = p + (long)(o.ok ? oc : 0) * SP; return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int r0) const {
-        f32x4 v = zero4();
-        if (!o.ok || r0 >= R) return v;
-        if constexpr (SP % 4 == 0) {
-            const int b = r0 / SP, sp = r0 % SP;
-            return *reinterpret_cast<const f32x4*>(o.cp + (long)b * OC * SP + sp);
+    struct Inner { long off; int m; };               // position group -> offset of its (clamped) first float, flags
+    __device__ __forceinline__ Inner prep_inner(int r0) const {
+        const bool in = r0 < R;
+        const int rc = in ? r0 : 0;
+        const int b = rc / SPP, sp = rc % SPP;
+        const bool tail = TAIL != 0 && sp + 4 > SP;                  // sp == SPP - 4
+        Inner i; i.off = (long)b * OC * SP + (tail ? SP - 4 : sp); i.m = (int)in | ((int)tail << 1);
+        return i;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        meta = o.ok ? in.m : 0;
+        if constexpr (TAIL == 0) return *reinterpret_cast<const f32x4*>(o.cp + in.off);
+        else return *reinterpret_cast<const f32x4_u*>(o.cp + in.off);
+    }
+    __device__ static __forceinline__ f32x4 post(const f32x4& v, int meta) {
+        if constexpr (TAIL == 0) {
+            return sel4(meta & 1, v);
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int r = r0 + j;
-                if (r < R) { const int b = r / SP, sp = r % SP; v[j] = o.cp[(long)b * OC * SP + sp]; }
-            }
-            return v;
+            const bool tail = meta & 2;
+            f32x4 r;                                                  // tail: real positions are v[4-TAIL .. 3]
+            r[0] = tail ? v[4 - TAIL] : v[0];
+            r[1] = tail ? (TAIL > 1 ? v[(5 - TAIL) & 3] : 0.f) : v[1];
+            r[2] = tail ? (TAIL > 2 ? v[(6 - TAIL) & 3] : 0.f) : v[2];
+            r[3] = tail ? 0.f : v[3];
+            return sel4(meta & 1, r);
         }
     }
 };
@@ -137,7 +166,12 @@ struct DgradDy {   // N-operand: rows = input positions of one phase, k = (oc, a
         }
         return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int k0) const {
+    __device__ static __forceinline__ f32x4 post(const f32x4& v, int) { return v; }
+    struct Inner { int k0; };
+    __device__ __forceinline__ Inner prep_inner(int k0) const { return Inner{k0}; }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        const int k0 = in.k0;
+        meta = 1;
         f32x4 v = zero4();
         if (o.mask == 0u || k0 >= Kred) return v;
         if constexpr (G::TAPS % 4 == 0) {          // 4 consecutive k share one oc (Kred % 4 == 0)
@@ -196,12 +230,17 @@ struct DgradEpi {  // (m = c, n = pos) -> dX[b, c, iy, ix] = acc * (X[b,c,iy,ix]
 // padding positions are dropped by the epilogue (forward, dgrad) or multiplied by an exact zero from the
 // other operand (wgrad).
 // ==========================================================================================
-__device__ __forceinline__ f32x4 load4_unaligned(const float* q, const float* lo, const float* hi) {
-    if (q >= lo && q + 4 <= hi) return *reinterpret_cast<const f32x4_u*>(q);
-    f32x4 v = zero4();                                   // tensor edge: guarded scalar loads
-#pragma unroll
-    for (int j = 0; j < 4; ++j) if (q + j >= lo && q + j < hi) v[j] = q[j];
-    return v;
+// 4 floats from q where only q[0..2] are guaranteed inside the tensor [.., hi): the padded 4th position of a row
+// may fall one float behind the tensor's end.  Branch-free: fetch from min(q, hi-4); `clamped` tells post() to
+// shift the vector down by one.
+__device__ __forceinline__ f32x4 load4_tail_safe(const float* q, const float* hi, bool& clamped) {
+    clamped = q + 4 > hi;                                // can only be by one float
+    return *reinterpret_cast<const f32x4_u*>(clamped ? hi - 4 : q);
+}
+__device__ __forceinline__ f32x4 shift_down1(bool cl, const f32x4& v) {
+    f32x4 r;
+    r[0] = cl ? v[1] : v[0]; r[1] = cl ? v[2] : v[1]; r[2] = cl ? v[3] : v[2]; r[3] = cl ? 0.f : v[3];
+    return r;
 }
 
 // stride-1 im2col: element (kk = (c,ky,kx), padded position pp = (b, oy, oxp))
@@ -209,7 +248,7 @@ template <int KH, int KW, int H, int W, int OWP, bool INNER_K>
 struct Im2colPos {
     static constexpr bool INNER_IS_K = INNER_K;          // true: positions are the GEMM K (wgrad); false: rows (fwd)
     static constexpr int OH = H - KH + 1, OW = W - KW + 1, PP = OH * OWP, KK = KH * KW, HW = H * W;
-    static_assert(OWP % 4 == 0 && OWP >= OW, "padded row length");
+    static_assert(OWP % 4 == 0 && OWP >= OW && OWP - OW <= 1, "padded row length (at most one float of over-read)");
     const float* x; const float* x_end; int C; int RP; int Kc;
     struct Outer { int off; int ok; };
     __device__ __forceinline__ Outer prep(int kk) const {
@@ -218,11 +257,22 @@ struct Im2colPos {
         o.off = c * HW + (rem / KW) * W + (rem % KW);
         return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int p0) const {
-        if (!o.ok || p0 >= RP) return zero4();
-        const int b = p0 / PP, r = p0 % PP;
-        const float* q = x + (long)b * C * HW + o.off + (r / OWP) * W + (r % OWP);
-        return load4_unaligned(q, x, x_end);
+    struct Inner { long off; int ok; };              // padded position group -> offset of its window origin
+    __device__ __forceinline__ Inner prep_inner(int p0) const {
+        Inner in; in.ok = p0 < RP;
+        const int pc = in.ok ? p0 : 0;
+        const int b = pc / PP, r = pc % PP;
+        in.off = (long)b * C * HW + (r / OWP) * W + (r % OWP);
+        return in;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        bool cl;
+        const f32x4 v = load4_tail_safe(x + in.off + o.off, x_end, cl);
+        meta = (int)(o.ok && in.ok) | ((int)cl << 1);
+        return v;
+    }
+    __device__ static __forceinline__ f32x4 post(const f32x4& v, int meta) {
+        return sel4(meta & 1, shift_down1(meta & 2, v));
     }
 };
 
@@ -236,15 +286,28 @@ struct ConvOutPos {
     __device__ __forceinline__ Outer prep(int oc) const {
         Outer o; o.ok = oc < OC; o.cp = p + (long)(o.ok ? oc : 0) * SP; return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int p0) const {
-        if (!o.ok || p0 >= RP) return zero4();
-        const int b = p0 / PP, r = p0 % PP;
+    struct Inner { long off; int m; };
+    __device__ __forceinline__ Inner prep_inner(int p0) const {
+        static_assert(OWP - OW <= 1, "at most one padded position per row (load4_tail_safe shifts by one)");
+        const bool in = p0 < RP;
+        const int pc = in ? p0 : 0;
+        const int b = pc / PP, r = pc % PP;
         const int oy = r / OWP, ox0 = r % OWP;
-        if (ox0 >= OW) return zero4();
-        f32x4 v = load4_unaligned(o.cp + (long)b * OC * SP + oy * OW + ox0, p, p_end);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) if (ox0 + j >= OW) v[j] = 0.f;
+        Inner i; i.off = (long)b * OC * SP + oy * OW + ox0; i.m = (int)in | (ox0 << 2);
+        return i;
+    }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        bool cl;
+        const f32x4 v = load4_tail_safe(o.cp + in.off, p_end, cl);
+        meta = (o.ok ? in.m : (in.m & ~1)) | ((int)cl << 1);
         return v;
+    }
+    __device__ static __forceinline__ f32x4 post(const f32x4& raw, int meta) {
+        f32x4 v = shift_down1(meta & 2, raw);
+        const int ox0 = meta >> 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (ox0 + j < OW) ? v[j] : 0.f;
+        return sel4(meta & 1, v);
     }
 };
 

@@ -22,6 +22,7 @@
 //     tile t and written to the other LDS stage afterwards; one barrier per K tile.
 //   * optional split-K over blockIdx.z into per-slice slabs (deterministic fixed-order reduce).
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 namespace acktr {
@@ -39,7 +40,12 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 // Operand concept:
 //   static constexpr bool INNER_IS_K;
 //   struct Outer;  Outer prep(int outer) const;
-//   f32x4 ld4(const Outer&, int inner4) const;     // 4 consecutive "inner" elements, 0-filled OOB
+//   struct Inner;  Inner prep_inner(int inner4) const;      // decode of the inner index; for row-contiguous operands
+//                                                           // it is K-invariant and evaluated ONCE per thread
+//   f32x4 ld4(const Outer&, const Inner&, int& meta) const; // RAW 4 consecutive "inner" elements from a safe address
+//   static f32x4 post(const f32x4& raw, int meta);          // bounds select / shifts, applied when the registers are
+//                                                           // committed to LDS -- never right behind the load, so that
+//                                                           // the loads of a whole tile stay in flight together
 //   INNER_IS_K : outer = row (m or n), inner = k        !INNER_IS_K : outer = k, inner = row
 // ------------------------------------------------------------------------------------------
 template <int BR, class Op>
@@ -52,35 +58,47 @@ struct OperandTile {
     // state of that k (an im2col position decode + gather-index load) is prepared once per thread per K tile
     static_assert(RQ % 8 == 0, "row tile must be a multiple of 32");
 
-    f32x4 regs[UNITS];
+    f32x4 regs[2][UNITS];                            // two tiles in flight (register-staged prefetch, depth 2)
+    int meta[2][UNITS];
     typename Op::Outer outer[Op::INNER_IS_K ? UNITS : 1];
+    typename Op::Inner inner[Op::INNER_IS_K ? 1 : UNITS];     // row-contiguous: the rows' decode never changes
 
     __device__ __forceinline__ void init(const Op& op, int row_base, int tid) {
         if constexpr (Op::INNER_IS_K) {
 #pragma unroll
             for (int u = 0; u < UNITS; ++u) outer[u] = op.prep(row_base + (tid >> 3) + 32 * u);
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNITS; ++u) inner[u] = op.prep_inner(row_base + 4 * ((tid & 7) + 8 * u));
         }
     }
+    template <int P>
     __device__ __forceinline__ void load(const Op& op, int row_base, int k_base, int tid) {
         if constexpr (Op::INNER_IS_K) {
-            const int k0 = k_base + 4 * (tid & 7);
+            const typename Op::Inner in = op.prep_inner(k_base + 4 * (tid & 7));
 #pragma unroll
-            for (int u = 0; u < UNITS; ++u) regs[u] = op.ld4(outer[u], k0);
+            for (int u = 0; u < UNITS; ++u) regs[P][u] = op.ld4(outer[u], in, meta[P][u]);
         } else {
             const typename Op::Outer o = op.prep(k_base + (tid >> 3));
 #pragma unroll
-            for (int u = 0; u < UNITS; ++u) regs[u] = op.ld4(o, row_base + 4 * ((tid & 7) + 8 * u));
+            for (int u = 0; u < UNITS; ++u) regs[P][u] = op.ld4(o, inner[u], meta[P][u]);
         }
     }
+    template <int P>
+    __device__ __forceinline__ void finish() {       // raw -> operand values (bounds select etc.)
+#pragma unroll
+        for (int u = 0; u < UNITS; ++u) regs[P][u] = Op::post(regs[P][u], meta[P][u]);
+    }
+    template <int P>
     __device__ __forceinline__ void store(float* s, int tid) const {
         if constexpr (Op::INNER_IS_K) {
 #pragma unroll
             for (int u = 0; u < UNITS; ++u)
-                *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * u) * PK + 4 * (tid & 7)) = regs[u];
+                *reinterpret_cast<f32x4*>(s + ((tid >> 3) + 32 * u) * PK + 4 * (tid & 7)) = regs[P][u];
         } else {
 #pragma unroll
             for (int u = 0; u < UNITS; ++u)
-                *reinterpret_cast<f32x4*>(s + (tid >> 3) * PITCH_R + 4 * ((tid & 7) + 8 * u)) = regs[u];
+                *reinterpret_cast<f32x4*>(s + (tid >> 3) * PITCH_R + 4 * ((tid & 7) + 8 * u)) = regs[P][u];
         }
     }
     // fragment for tile-local row `row`, k group base kk = 8q + 4h
@@ -145,56 +163,85 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
     f32x4 rs[MT::UNITS];
 #pragma unroll
     for (int u = 0; u < MT::UNITS; ++u) rs[u] = zero4();
-    auto rowsum_add = [&]() {
+    // Pipeline (depth 2): while tile kt is multiplied out of LDS, tile kt+1 sits in register set (kt+1)&1 waiting to
+    // be stored and tile kt+2 is in flight into the other set.  With one tile of look-ahead every K step exposed a
+    // full memory latency: the short reductions of this workload (a few K tiles per workgroup) ran latency-bound.
+    // request tile t into register set P.  UNCONDITIONAL (past the end the last tile is simply requested again and
+    // never committed): behind a branch the compiler cannot count the loads in flight and drains them all.
+    auto issue = [&](auto P, int t) {
+        const int tc = t < nk ? t : (nk > 0 ? nk - 1 : 0);       // (an empty K slice requests k >= K: masked, safe)
+        mt.template load<decltype(P)::value>(mop, m0, kbeg + tc * GK, tid);
+        nt.template load<decltype(P)::value>(nop, n0, kbeg + tc * GK, tid);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // register set P (tile t) -> LDS stage t&1 (+ bias row sums).  Also unconditional: past the end it stores the
+    // re-requested last tile into a stage that nobody reads any more.
+    auto commit = [&](auto P, int t) {
+        mt.template finish<decltype(P)::value>();
+        nt.template finish<decltype(P)::value>();
         if constexpr (Epi::HAS_ROWSUM) {
-            if (do_rowsum) {
+            if (do_rowsum && t < nk) {
 #pragma unroll
-                for (int u = 0; u < MT::UNITS; ++u) rs[u] += mt.regs[u];
+                for (int u = 0; u < MT::UNITS; ++u) rs[u] += mt.regs[decltype(P)::value][u];
             }
         }
+        float* d = smem + (t & 1) * STAGE;
+        mt.template store<decltype(P)::value>(d, tid);
+        nt.template store<decltype(P)::value>(d + MT::SMEM, tid);
     };
-
-    if (nk > 0) {
-        mt.load(mop, m0, kbeg, tid);
-        nt.load(nop, n0, kbeg, tid);
-        rowsum_add();
-        mt.store(smem, tid);
-        nt.store(smem + MT::SMEM, tid);
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
+    auto multiply = [&](int kt) {
         const float* sM = smem + (kt & 1) * STAGE;
         const float* sN = sM + MT::SMEM;
-        const bool more = (kt + 1 < nk);
-        if (more) {
-            mt.load(mop, m0, kbeg + (kt + 1) * GK, tid);
-            nt.load(nop, n0, kbeg + (kt + 1) * GK, tid);
-            rowsum_add();
-        }
+        // fragments are fetched from LDS one k group ahead of the MFMAs that use them
+        f32x4 af[2][TM], bf[2][TN];
+        auto load_frags = [&](int q) {
+            const int kk = 8 * q + 4 * lh;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) af[q & 1][a] = MT::frag(sM, wm * (TM * 32) + a * 32 + li, kk);
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bf[q & 1][b] = NT::frag(sN, wn * (TN * 32) + b * 32 + li, kk);
+        };
+        load_frags(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < GK / 8; ++q) {
-            const int kk = 8 * q + 4 * lh;
-            f32x4 af[TM], bf[TN];
-#pragma unroll
-            for (int a = 0; a < TM; ++a) af[a] = MT::frag(sM, wm * (TM * 32) + a * 32 + li, kk);
-#pragma unroll
-            for (int b = 0; b < TN; ++b) bf[b] = NT::frag(sN, wn * (TN * 32) + b * 32 + li, kk);
+            if (q + 1 < GK / 8) load_frags(q + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int a = 0; a < TM; ++a)
 #pragma unroll
                     for (int b = 0; b < TN; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[q & 1][a][t], bf[q & 1][b][t], acc[a][b], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) {
-            float* dM = smem + ((kt + 1) & 1) * STAGE;
-            mt.store(dM, tid);
-            nt.store(dM + MT::SMEM, tid);
-        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    issue(P0{}, 0);
+    issue(P1{}, 1);
+    commit(P0{}, 0);
+    issue(P0{}, 2);
+    __syncthreads();
+
+    // the loop body is one straight line (no exits, no conditional memory operations), so the compiler's count of
+    // outstanding loads stays exact across the back edge
+    const int npairs = nk / 2;
+    for (int i = 0; i < npairs; ++i) {
+        const int kt = 2 * i;
+        multiply(kt);                 // set 1 holds tile kt+1, set 0 is receiving tile kt+2
+        commit(P1{}, kt + 1);
+        issue(P1{}, kt + 3);
+        __syncthreads();
+        multiply(kt + 1);             // set 0 holds tile kt+2, set 1 is receiving tile kt+3
+        commit(P0{}, kt + 2);
+        issue(P0{}, kt + 4);
         __syncthreads();
     }
+    if (nk & 1) multiply(nk - 1);
+    __syncthreads();                  // LDS is reused by the row-sum reduction below
 
     if constexpr (Epi::HAS_ROWSUM) {
         if (do_rowsum) {
@@ -301,40 +348,74 @@ int launch_gemm_z(const MOp& mop, const NOp& nop, const Epi& epi, int M, int N, 
 // ==========================================================================================
 // Dense operands
 // ==========================================================================================
-// element (row, k) at p[row*ld + k]  (k contiguous)
-struct DenseKC {
+// Loader rule: the common path of every operand is BRANCH-FREE -- one unconditional 16-byte load from a clamped
+// (always valid) address; the bounds predicate travels in `meta` and is applied by post() at LDS-store time.
+// Loads under per-lane branches end up in separate basic blocks (they cannot be batched, and the compiler drains
+// the memory counter at every join); a select right behind the load makes the wave wait for it on the spot.
+__device__ __forceinline__ f32x4 sel4(bool ok, const f32x4& v) {
+    f32x4 r;
+    r[0] = ok ? v[0] : 0.f; r[1] = ok ? v[1] : 0.f; r[2] = ok ? v[2] : 0.f; r[3] = ok ? v[3] : 0.f;
+    return r;
+}
+
+// element (row, k) at p[row*ld + k]  (k contiguous).  VEC: p 16-byte aligned, ld % 4 == 0, K % 4 == 0.
+template <bool VEC>
+struct DenseKCT {
     static constexpr bool INNER_IS_K = true;
-    const float* p; int rows; int K; long ld; int vec;
+    const float* p; int rows; int K; long ld;
     struct Outer { const float* rp; int ok; };
     __device__ __forceinline__ Outer prep(int row) const {
         Outer o; o.ok = row < rows; o.rp = p + (long)(o.ok ? row : 0) * ld; return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int k0) const {
-        f32x4 v = zero4();
-        if (!o.ok || k0 >= K) return v;
-        if (vec && k0 + 3 < K) return *reinterpret_cast<const f32x4*>(o.rp + k0);
+    struct Inner { int k0; };
+    __device__ __forceinline__ Inner prep_inner(int k0) const { return Inner{k0}; }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        const int k0 = in.k0;
+        if constexpr (VEC) {
+            const bool ok = o.ok && k0 < K;
+            meta = ok;
+            return *reinterpret_cast<const f32x4*>(o.rp + (ok ? k0 : 0));
+        } else {
+            meta = 1;
+            f32x4 v = zero4();
+            if (!o.ok || k0 >= K) return v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (k0 + j < K) v[j] = o.rp[k0 + j];
-        return v;
+            for (int j = 0; j < 4; ++j) if (k0 + j < K) v[j] = o.rp[k0 + j];
+            return v;
+        }
     }
+    __device__ static __forceinline__ f32x4 post(const f32x4& v, int meta) { return sel4(meta & 1, v); }
 };
-// element (row, k) at p[k*ld + row]  (row contiguous)
-struct DenseRC {
+// element (row, k) at p[k*ld + row]  (row contiguous).  VEC: p 16-byte aligned, ld % 4 == 0, rows % 4 == 0.
+template <bool VEC>
+struct DenseRCT {
     static constexpr bool INNER_IS_K = false;
-    const float* p; int rows; int K; long ld; int vec;
+    const float* p; int rows; int K; long ld;
     struct Outer { const float* kp; int ok; };
     __device__ __forceinline__ Outer prep(int k) const {
         Outer o; o.ok = k < K; o.kp = p + (long)(o.ok ? k : 0) * ld; return o;
     }
-    __device__ __forceinline__ f32x4 ld4(const Outer& o, int r0) const {
-        f32x4 v = zero4();
-        if (!o.ok || r0 >= rows) return v;
-        if (vec && r0 + 3 < rows) return *reinterpret_cast<const f32x4*>(o.kp + r0);
+    struct Inner { int r0; };
+    __device__ __forceinline__ Inner prep_inner(int r0) const { return Inner{r0}; }
+    __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
+        const int r0 = in.r0;
+        if constexpr (VEC) {
+            const bool ok = o.ok && r0 < rows;
+            meta = ok;
+            return *reinterpret_cast<const f32x4*>(o.kp + (ok ? r0 : 0));
+        } else {
+            meta = 1;
+            f32x4 v = zero4();
+            if (!o.ok || r0 >= rows) return v;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = o.kp[r0 + j];
-        return v;
+            for (int j = 0; j < 4; ++j) if (r0 + j < rows) v[j] = o.kp[r0 + j];
+            return v;
+        }
     }
+    __device__ static __forceinline__ f32x4 post(const f32x4& v, int meta) { return sel4(meta & 1, v); }
 };
+using DenseKC = DenseKCT<true>;      // the conv / KFAC call sites use the vector forms (their shapes qualify)
+using DenseRC = DenseRCT<true>;
 static inline int vec_ok(const float* p, long ld) { return (((uintptr_t)p & 15) == 0) && (ld % 4 == 0); }
 
 // ==========================================================================================

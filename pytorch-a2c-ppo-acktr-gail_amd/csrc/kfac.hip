@@ -23,7 +23,7 @@ template <int KH, int KW, int S, int H, int W>
 static int cov_a_conv_t(const float* x, const int64_t* idx, int B, int C, float alpha, float* out, float* ws,
                         long ws_floats, hipStream_t s) {
     using Patch = Im2col<KH, KW, S, H, W, false>;
-    const int Kc = C * KH * KW, R = B * Patch::SP;
+    const int Kc = C * KH * KW, R = B * Patch::SPP;      // reduction over positions, images padded to SPP (zeros)
     Patch pop{x, idx, C, (long)C * H * W, R, Kc};
     const long tiles = (long)cdiv(Kc, 128) * cdiv(Kc, 128);
     long max_by_ws = ws_floats / ((long)Kc * Kc) - SLAB_GROUP_EXTRA;
@@ -44,7 +44,7 @@ static int cov_a_conv_t(const float* x, const int64_t* idx, int B, int C, float 
 template <int SP>
 static int cov_g_conv_t(const float* dy, int B, int OC, float alpha, float* out, float* ws, long ws_floats,
                         hipStream_t s) {
-    const int R = B * SP;
+    const int R = B * ConvOutKC<SP>::SPP;               // positions of an image padded to a multiple of 4 (zeros)
     ConvOutKC<SP> gop{dy, OC, R};
     long max_by_ws = ws_floats / ((long)OC * OC) - SLAB_GROUP_EXTRA;
     int ns = pick_slices(1, R, max_by_ws < 1 ? 1 : max_by_ws);

@@ -123,26 +123,36 @@ long gemm_tiles(int M, int N) {
 
 // Generic C[M,N] (row major, ldc) = A(m,k) * B(n,k) with explicit element strides per operand:
 // an operand is "k contiguous" (stride_k == 1) or "row contiguous" (stride_row == 1).
+template <bool VEC>
+static int gemm_rowmajor_t(const float* a, long a_srow, long a_sk, const float* b, long b_srow, long b_sk,
+                           const RowMajorEpi& epi, int M, int N, int K, int nslices, hipStream_t s) {
+    const bool a_kc = (a_sk == 1), b_kc = (b_sk == 1);
+    if (a_kc && b_kc) {
+        DenseKCT<VEC> A{a, M, K, a_srow}, B{b, N, K, b_srow};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    } else if (a_kc && !b_kc) {
+        DenseKCT<VEC> A{a, M, K, a_srow};
+        DenseRCT<VEC> B{b, N, K, b_sk};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    } else if (!a_kc && b_kc) {
+        DenseRCT<VEC> A{a, M, K, a_sk};
+        DenseKCT<VEC> B{b, N, K, b_srow};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    } else {
+        DenseRCT<VEC> A{a, M, K, a_sk}, B{b, N, K, b_sk};
+        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
+    }
+}
 int gemm_rowmajor(const float* a, long a_srow, long a_sk, const float* b, long b_srow, long b_sk, const RowMajorEpi& epi,
                   int M, int N, int K, int nslices, hipStream_t s) {
     const bool a_kc = (a_sk == 1), b_kc = (b_sk == 1);
     if (!a_kc && a_srow != 1) { set_error("gemm: operand A must be contiguous along k or rows"); return -1; }
     if (!b_kc && b_srow != 1) { set_error("gemm: operand B must be contiguous along k or rows"); return -1; }
-    if (a_kc && b_kc) {
-        DenseKC A{a, M, K, a_srow, vec_ok(a, a_srow)}, B{b, N, K, b_srow, vec_ok(b, b_srow)};
-        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
-    } else if (a_kc && !b_kc) {
-        DenseKC A{a, M, K, a_srow, vec_ok(a, a_srow)};
-        DenseRC B{b, N, K, b_sk, vec_ok(b, b_sk)};
-        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
-    } else if (!a_kc && b_kc) {
-        DenseRC A{a, M, K, a_sk, vec_ok(a, a_sk)};
-        DenseKC B{b, N, K, b_srow, vec_ok(b, b_srow)};
-        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
-    } else {
-        DenseRC A{a, M, K, a_sk, vec_ok(a, a_sk)}, B{b, N, K, b_sk, vec_ok(b, b_sk)};
-        return gemm_dispatch(A, B, epi, M, N, K, nslices, s);
-    }
+    // vector (branch-free) loaders need 16-byte aligned rows and a contiguous extent that is a multiple of 4
+    const bool va = a_kc ? (vec_ok(a, a_srow) && K % 4 == 0) : (vec_ok(a, a_sk) && M % 4 == 0);
+    const bool vb = b_kc ? (vec_ok(b, b_srow) && K % 4 == 0) : (vec_ok(b, b_sk) && N % 4 == 0);
+    if (va && vb) return gemm_rowmajor_t<true>(a, a_srow, a_sk, b, b_srow, b_sk, epi, M, N, K, nslices, s);
+    return gemm_rowmajor_t<false>(a, a_srow, a_sk, b, b_srow, b_sk, epi, M, N, K, nslices, s);
 }
 
 int pick_slices(long tiles, long K, long max_by_ws) {

@@ -98,12 +98,104 @@ def cpu_baseline(ro_cpu, seed):
                        % (T, N, T * N // PPO_HP['num_mini_batch'], dt)), losses
 
 
+def _timed_updates(agent, rs, n, seed0):
+    """ms of each of n consecutive update() calls (device-synchronised around every call)."""
+    out = []
+    for i in range(n):
+        torch.manual_seed(seed0 + i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        agent.update(rs)
+        torch.cuda.synchronize()
+        out.append((time.perf_counter() - t0) * 1e3)
+    return out
+
+
+def side_metrics(device):
+    """The other figures BASELINE.json's metric names, on one GPU (SURVEY.md 8(d) definitions):
+    A2C update (configs[1]: 16 procs x 5 steps), ACKTR update + KFAC step ms (configs[3]: 32 procs x 20 steps,
+    Ts=1, Tf=10), and the GAE scan at the large-scan stress size of configs[4] (2048 steps x 1024 procs)."""
+    import statistics
+    from a2c_ppo_acktr import algo
+    from a2c_ppo_acktr.model import Policy
+    from a2c_ppo_acktr.storage import RolloutStorage
+    out = {}
+    # ---- A2C, B = 80
+    T, N = 5, 16
+    ro = synth_rollouts(T, N, device, seed=21)
+    torch.manual_seed(8)
+    pol = Policy((4, 84, 84), Discrete(ACTIONS)); pol.to(device)
+    agent = algo.A2C_ACKTR(pol, 0.5, 0.01, lr=7e-4, eps=1e-5, alpha=0.99, max_grad_norm=0.5)
+    rs = fill_storage(ro, device)
+    rs.compute_returns(ro['next_value'], False, 0.99, 0.95, False)
+    _timed_updates(agent, rs, 3, 400)
+    ms = _timed_updates(agent, rs, 20, 410)
+    out['a2c_update'] = dict(workload='A2C_ACKTR.update NatureCNN, 16 procs x 5 steps (B=80), RMSprop',
+                             ms_median=round(statistics.median(ms), 3),
+                             samples_per_s=round(T * N / (statistics.median(ms) * 1e-3), 1))
+    # ---- ACKTR, B = 640: 23 updates = eigendecompositions at optimizer steps 0, 10, 20
+    T, N = 20, 32
+    ro = synth_rollouts(T, N, device, seed=22)
+    torch.manual_seed(9)
+    pol = Policy((4, 84, 84), Discrete(ACTIONS)); pol.to(device)
+    agent = algo.A2C_ACKTR(pol, 0.5, 0.01, acktr=True)
+    rs = fill_storage(ro, device)
+    rs.compute_returns(ro['next_value'], False, 0.99, 0.95, False)
+    opt = agent.optimizer
+    step_ms, inner = [], opt.step
+
+    def timed_step(*a, **k):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        r = inner(*a, **k)
+        torch.cuda.synchronize()
+        step_ms.append(((opt.steps - 1) % opt.Tf == 0, (time.perf_counter() - t0) * 1e3))
+        return r
+    _timed_updates(agent, rs, 2, 500)                       # warm-up (includes the step-0 eigendecomposition)
+    opt.step = timed_step
+    ms = _timed_updates(agent, rs, 21, 510)                 # optimizer steps 2..22: eig at 10 and 20
+    opt.step = inner
+    eig = [m for is_eig, m in step_ms if is_eig]
+    plain = [m for is_eig, m in step_ms if not is_eig]
+    out['acktr_update'] = dict(workload='A2C_ACKTR(acktr=True).update NatureCNN, 32 procs x 20 steps (B=640), Ts=1 Tf=10',
+                               ms_mean_21_updates=round(sum(ms) / len(ms), 3),
+                               samples_per_s=round(T * N * len(ms) / (sum(ms) * 1e-3), 1),
+                               kfac_step_ms=dict(with_eig=round(statistics.median(eig), 3) if eig else None,
+                                                 without_eig=round(statistics.median(plain), 3), n_eig=len(eig)))
+    # ---- GAE scan (20 B per element: GAE + proper time limits): the stress size of configs[4], where the serial
+    # chain of 2048 steps on only 1024 lanes is the floor, and a wide rollout where HBM is
+    for T, N in ((2048, 1024), (512, 65536)):
+        g = torch.Generator(device=device).manual_seed(23)
+        rs = RolloutStorage(1, 1, (1,), Discrete(ACTIONS), 1)
+        rs.num_steps = T
+        rs.rewards = torch.randn(T, N, 1, device=device, generator=g)
+        rs.value_preds = torch.randn(T + 1, N, 1, device=device, generator=g)
+        rs.returns = torch.zeros(T + 1, N, 1, device=device)
+        rs.masks = (torch.rand(T + 1, N, 1, device=device, generator=g) < 0.99).float()
+        rs.bad_masks = (torch.rand(T + 1, N, 1, device=device, generator=g) < 0.995).float()
+        nv = torch.randn(N, 1, device=device, generator=g)
+        for _ in range(3):
+            rs.compute_returns(nv, True, 0.99, 0.95, True)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(20):
+            rs.compute_returns(nv, True, 0.99, 0.95, True)
+        ev1.record()
+        torch.cuda.synchronize()
+        ms1 = ev0.elapsed_time(ev1) / 20
+        out['gae_scan_%dx%d' % (T, N)] = dict(ms=round(ms1, 4), algorithmic_bytes=T * N * 20,
+                                              gbps=round(T * N * 20 / (ms1 * 1e-3) / 1e9, 1), hbm_peak_gbps=8000)
+        del rs
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=5)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-side-metrics', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -196,6 +288,11 @@ def main():
                    gae_scan=dict(T=T_STEPS, N=N_global, ms=round(scan_ms, 4),
                                  gbps=round(T_STEPS * N_global * 20 / (scan_ms * 1e-3) / 1e9, 2)),
                    losses=[round(x, 6) for x in losses])
+        if world == 1 and not args.no_side_metrics:
+            try:
+                out['side_metrics'] = side_metrics(device)
+            except Exception as e:                       # never lose the headline line over a side figure
+                out['side_metrics'] = dict(error=repr(e))
         if not args.no_cpu_baseline:
             keep = {k: v[:, :PROCS_PER_GPU].cpu() if v.dim() == 3 or v.dim() == 5 else v[:PROCS_PER_GPU].cpu()
                     for k, v in ro.items()}

@@ -27,13 +27,34 @@ constexpr int SCAN_TE = 32;   // environments per workgroup
 constexpr int SCAN_TC = 64;   // time steps per chunk
 constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_EPT = SCAN_TE * SCAN_TC / SCAN_THREADS;   // elements per thread per chunk (8)
+constexpr int SCAN_PITCH = SCAN_TC + 4;                      // LDS row (one environment's chunk) pitch, 16-byte multiple
+typedef float scan_f4 __attribute__((ext_vector_type(4)));
 
+template <bool GAE, bool PROPER>
+struct ScanCfg {
+    static constexpr int NARR = PROPER ? 4 : (GAE ? 3 : 2);
+    static constexpr int IN_FLOATS = 2 * NARR * SCAN_TE * SCAN_PITCH;     // double-buffered chain operands
+    static constexpr int OUT_FLOATS = 2 * SCAN_TE * SCAN_PITCH;           // double-buffered results
+    static constexpr int LDS_BYTES = (IN_FLOATS + OUT_FLOATS) * (int)sizeof(float);
+};
+
+// Roles inside a workgroup, per 64-step chunk c (all overlapped, one barrier per chunk):
+//   all 4 waves : request chunk c+1 from HBM into registers (branch-free, 40 loads in flight per thread)
+//   wave 0      : the dependent chain of chunk c, operands and results through LDS as 16-byte vectors laid out
+//                 time-contiguous per environment (one ds_read_b128 = 4 steps of one operand)
+//   waves 1..3  : stream the results of chunk c-1 from LDS to HBM (coalesced 128-byte rows)
+//   all 4 waves : pre-compute chunk c+1's carry-independent terms into the other LDS buffer
 template <bool GAE, bool PROPER>
 __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
     const float* rewards, float* value_preds, float* returns, const float* masks, const float* bad_masks,
     const float* next_value, int T, int N, float g, float gl) {
-    constexpr int NARR = PROPER ? 4 : (GAE ? 3 : 2);
-    __shared__ float lds[2][NARR][SCAN_TC][SCAN_TE];
+    using Cfg = ScanCfg<GAE, PROPER>;
+    constexpr int NARR = Cfg::NARR;
+    extern __shared__ __attribute__((aligned(16))) float scan_lds[];
+    float* lin = scan_lds;                          // [2][NARR][SCAN_TE][SCAN_PITCH]
+    float* lout = scan_lds + Cfg::IN_FLOATS;        // [2][SCAN_TE][SCAN_PITCH]
+    auto in_at = [&](int buf, int k, int le) { return lin + ((buf * NARR + k) * SCAN_TE + le) * SCAN_PITCH; };
+    auto out_at = [&](int buf, int le) { return lout + (buf * SCAN_TE + le) * SCAN_PITCH; };
 
     const int tid = threadIdx.x;
     const int e0 = blockIdx.x * SCAN_TE;
@@ -48,20 +69,23 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
 
     float st[SCAN_EPT][5];
 
+    // branch-free: out-of-range (t < 0 on the last chunk, n >= N on the last workgroup) elements are fetched from a
+    // clamped, valid address and never stored, so the loads of a chunk are issued back to back and stay in flight
+    // during the serial scan
     auto issue_loads = [&](int c) {
         const int tlo = T - (c + 1) * SCAN_TC;
 #pragma unroll
         for (int i = 0; i < SCAN_EPT; ++i) {
             const int e = tid + SCAN_THREADS * i;
             const int j = e / SCAN_TE, le = e % SCAN_TE;
-            const int t = tlo + j, n = e0 + le;
-            const bool ok = (t >= 0) && (n < N);
+            const int t = (tlo + j) < 0 ? 0 : tlo + j;
+            const int n = (e0 + le) < N ? e0 + le : N - 1;
             const long o = (long)t * N + n;
-            st[i][0] = ok ? rewards[o] : 0.f;
-            st[i][1] = ok ? masks[o + N] : 0.f;                       // masks[t+1]
-            if (GAE || PROPER) st[i][2] = ok ? value_preds[o] : 0.f;  // V[t]
-            if (GAE) st[i][3] = ok ? ((t == T - 1) ? next_value[n] : value_preds[o + N]) : 0.f;   // V[t+1]
-            if (PROPER) st[i][4] = ok ? bad_masks[o + N] : 0.f;       // bad_masks[t+1]
+            st[i][0] = rewards[o];
+            st[i][1] = masks[o + N];                                  // masks[t+1]
+            if (GAE || PROPER) st[i][2] = value_preds[o];             // V[t]
+            if (GAE) st[i][3] = value_preds[o + N];                   // V[t+1]  (t = T-1 is patched below)
+            if (PROPER) st[i][4] = bad_masks[o + N];                  // bad_masks[t+1]
         }
     };
     auto stage_to_lds = [&](int buf) {
@@ -73,57 +97,92 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
             if (GAE) {
                 // delta = (r + (g*V[t+1])*m) - V[t]          storage.py:77-79 / 95-97
                 const float delta = ((((r) + (((((g) * (st[i][3]))) * (m))))) - (st[i][2]));
-                lds[buf][0][j][le] = delta;
-                lds[buf][1][j][le] = ((gl) * (m));                 // (gamma*lambda)*mask
-                lds[buf][2][j][le] = st[i][2];
-                if (PROPER) lds[buf][3][j][le] = st[i][4];
+                in_at(buf, 0, le)[j] = delta;
+                in_at(buf, 1, le)[j] = ((gl) * (m));                 // (gamma*lambda)*mask
+                in_at(buf, 2, le)[j] = st[i][2];
+                if (PROPER) in_at(buf, 3, le)[j] = st[i][4];
             } else {
-                lds[buf][0][j][le] = m;
-                lds[buf][1][j][le] = r;
+                in_at(buf, 0, le)[j] = m;
+                in_at(buf, 1, le)[j] = r;
                 if (PROPER) {
-                    lds[buf][2][j][le] = st[i][4];
-                    lds[buf][3][j][le] = ((((1.0f) - (st[i][4]))) * (st[i][2]));   // (1-b)*V[t]
+                    in_at(buf, 2, le)[j] = st[i][4];
+                    in_at(buf, 3, le)[j] = ((((1.0f) - (st[i][4]))) * (st[i][2]));   // (1-b)*V[t]
                 }
             }
         }
     };
+    // results of chunk c (LDS) -> returns rows; `first`/`step` select the participating threads
+    auto flush = [&](int c, int first, int step) {
+        const int buf = c & 1;
+        const int tlo = T - (c + 1) * SCAN_TC;
+        for (int e = first; e < SCAN_TE * SCAN_TC; e += step) {
+            const int j = e / SCAN_TE, le = e % SCAN_TE;
+            if (tlo + j >= 0 && e0 + le < N) returns[(long)(tlo + j) * N + e0 + le] = out_at(buf, le)[j];
+        }
+    };
 
     issue_loads(0);
+    if (GAE) {      // V[T]: the reference reads next_value there (written above, possibly by another lane: use the source)
+#pragma unroll
+        for (int i = 0; i < SCAN_EPT; ++i) {
+            const int e = tid + SCAN_THREADS * i;
+            const int j = e / SCAN_TE, le = e % SCAN_TE;
+            const int n = (e0 + le) < N ? e0 + le : N - 1;
+            if (j == SCAN_TC - 1) st[i][3] = next_value[n];
+        }
+    }
     stage_to_lds(0);
     __syncthreads();
 
     float carry = 0.f;   // gae (GAE) or returns[t+1] (RET)
-    if (!GAE && tid < SCAN_TE && e0 + tid < N) carry = next_value[e0 + tid];
+    if (!GAE && tid < SCAN_TE) carry = next_value[(e0 + tid) < N ? e0 + tid : N - 1];
 
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) issue_loads(c + 1);      // in flight during the serial scan below
+        issue_loads(c + 1 < nchunks ? c + 1 : c);     // unconditional (the last chunk is re-requested and dropped)
 
-        if (tid < SCAN_TE) {                          // wave 0, lanes 0..31: the dependent chain
-            const int n = e0 + tid;
-            const int tlo = T - (c + 1) * SCAN_TC;
-            float* out = returns + (long)tlo * N + n;
-#pragma unroll 8
-            for (int j = SCAN_TC - 1; j >= 0; --j) {
-                const float x0 = lds[buf][0][j][tid];
-                const float x1 = lds[buf][1][j][tid];
-                float res;
-                if (GAE) {
-                    carry = ((x0) + (((x1) * (carry))));                 // gae = delta + (gl*m)*gae
-                    if (PROPER) carry = ((carry) * (lds[buf][3][j][tid]));   // gae *= bad_mask
-                    res = ((carry) + (lds[buf][2][j][tid]));                 // R = gae + V[t]
-                } else {
-                    carry = ((((((carry) * (g))) * (x0))) + (x1));   // (R*g)*m + r
-                    if (PROPER)
-                        carry = ((((carry) * (lds[buf][2][j][tid]))) + (lds[buf][3][j][tid]));
-                    res = carry;
+        if (tid < 64) {
+            if (tid < SCAN_TE) {                      // wave 0, lanes 0..31: the dependent chain
+                const float* p0 = in_at(buf, 0, tid);
+                const float* p1 = in_at(buf, 1, tid);
+                const float* p2 = in_at(buf, NARR > 2 ? 2 : 0, tid);
+                const float* p3 = in_at(buf, NARR > 3 ? 3 : 0, tid);
+                float* po = out_at(buf, tid);
+                scan_f4 a0[2], a1[2], a2[2], a3[2];
+                auto fetch = [&](int set, int j0) {
+                    a0[set] = *reinterpret_cast<const scan_f4*>(p0 + j0);
+                    a1[set] = *reinterpret_cast<const scan_f4*>(p1 + j0);
+                    if (NARR > 2) a2[set] = *reinterpret_cast<const scan_f4*>(p2 + j0);
+                    if (NARR > 3) a3[set] = *reinterpret_cast<const scan_f4*>(p3 + j0);
+                };
+                fetch(0, SCAN_TC - 4);
+#pragma unroll
+                for (int q = SCAN_TC / 4 - 1; q >= 0; --q) {
+                    const int set = (SCAN_TC / 4 - 1 - q) & 1;
+                    if (q > 0) fetch(set ^ 1, 4 * (q - 1));          // next 4 steps' operands while this chain runs
+                    scan_f4 res;
+#pragma unroll
+                    for (int u = 3; u >= 0; --u) {
+                        if (GAE) {
+                            carry = ((a0[set][u]) + (((a1[set][u]) * (carry))));     // gae = delta + (gl*m)*gae
+                            if (PROPER) carry = ((carry) * (a3[set][u]));            // gae *= bad_mask
+                            res[u] = ((carry) + (a2[set][u]));                       // R = gae + V[t]
+                        } else {
+                            carry = ((((((carry) * (g))) * (a0[set][u]))) + (a1[set][u]));   // (R*g)*m + r
+                            if (PROPER) carry = ((((carry) * (a2[set][u]))) + (a3[set][u]));
+                            res[u] = carry;
+                        }
+                    }
+                    *reinterpret_cast<scan_f4*>(po + 4 * q) = res;
                 }
-                if (tlo + j >= 0 && n < N) out[(long)j * N] = res;
             }
+        } else if (c > 0) {
+            flush(c - 1, tid - 64, SCAN_THREADS - 64);               // waves 1..3 write out the previous chunk
         }
-        if (c + 1 < nchunks) stage_to_lds(buf ^ 1);
+        stage_to_lds(buf ^ 1);
         __syncthreads();
     }
+    flush(nchunks - 1, tid, SCAN_THREADS);
 }
 
 // ---------------------------------------------------------------------------
@@ -208,9 +267,19 @@ extern "C" int acktr_compute_returns_f32(const float* rewards, float* value_pred
     ACKTR_ARG((long)(T + 1) * N < (1L << 31), "compute_returns: (T+1)*N too large");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv(N, SCAN_TE)), block(SCAN_THREADS);
-#define LAUNCH(G, P)                                                                                          \
-    hipLaunchKernelGGL((returns_scan_kernel<G, P>), grid, block, 0, s, rewards, value_preds, returns, masks, \
-                       bad_masks, next_value, T, N, gamma32, gamma_lambda32)
+#define LAUNCH(G, P)                                                                                              \
+    do {                                                                                                          \
+        constexpr int lds_bytes = ScanCfg<G, P>::LDS_BYTES;                                                       \
+        static bool attr_set = false;                                                                             \
+        if (!attr_set && lds_bytes > 48 * 1024) {                                                                 \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(returns_scan_kernel<G, P>),          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);            \
+            ACKTR_ARG(e == hipSuccess, "compute_returns: hipFuncSetAttribute failed: %s", hipGetErrorString(e));  \
+            attr_set = true;                                                                                      \
+        }                                                                                                         \
+        hipLaunchKernelGGL((returns_scan_kernel<G, P>), grid, block, lds_bytes, s, rewards, value_preds, returns, \
+                           masks, bad_masks, next_value, T, N, gamma32, gamma_lambda32);                          \
+    } while (0)
     if (use_gae) {
         if (use_proper_time_limits) LAUNCH(true, true); else LAUNCH(true, false);
     } else {

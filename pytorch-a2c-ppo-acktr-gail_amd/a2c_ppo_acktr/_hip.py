@@ -34,6 +34,11 @@ class LossArgs(ctypes.Structure):
                 ('dlogstd', c_p), ('dlogstd_rows', c_p), ('logp_out', c_p), ('loss_acc', c_p),
                 ('workspace', c_p), ('workspace_bytes', c_l)]
 
+class EigJob(ctypes.Structure):
+    """struct acktr_eig_job (include/acktr_hip.h)"""
+    _fields_ = [('a_inout_qt', c_p), ('d', c_p), ('n', c_i), ('reserved', c_i)]
+
+
 # name -> (restype, argtypes); mirrors include/acktr_hip.h one to one
 _PROTOS = {
     'acktr_abi_version': (c_i, []),
@@ -73,6 +78,7 @@ _PROTOS = {
     'acktr_jacobi_max_n': (c_i, []),
     'acktr_sym_eig_jacobi_batched_f32': (c_i, [c_p, c_i, c_i, c_f, c_p]),
     'acktr_sym_eig_rocsolver_f32': (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p]),
+    'acktr_sym_eig_rocsolver_multi_f32': (c_i, [ctypes.POINTER(EigJob), c_i, c_p, c_p, c_f, c_p]),
     'acktr_kfac_precondition_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'acktr_kfac_kl_clip_f32': (c_i, [c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p]),
 }

@@ -165,7 +165,7 @@ class KFACOptimizer(optim.Optimizer):
         self.tmp1, self.tmp2 = z(mx), z(mx)
         self.nu_buf = z(2)
         nmax = max(max(m.na, m.ng) for m in self._mods)
-        self.e_work = z(nmax)
+        self.e_work = z(nmax)      # re-sized below to the sum over this rank's rocSOLVER factors
         self.info = torch.zeros(1, dtype=torch.int32, device=dev)
         # eigendecomposition work list: (run bucket, qt bucket, d bucket, offset, d offset, n), one per factor,
         # sharded layer-wise over the data-parallel ranks (greedy by n^3) -- SURVEY 8(e)
@@ -188,6 +188,12 @@ class KFACOptimizer(optim.Optimizer):
                 self._jac_max = max(self._jac_max, n)
             else:
                 self._big.append(w)
+        if self._big:              # host-side job table for the concurrent rocSOLVER solves (pointers are stable)
+            self.e_work = z(sum(w[5] for w in self._big))
+            self.info = torch.zeros(len(self._big), dtype=torch.int32, device=dev)
+            self._big_jobs = (_hip.EigJob * len(self._big))(*[
+                _hip.EigJob(qt.data_ptr() + 4 * off, dfl.data_ptr() + 4 * doff, n, 0)
+                for run, qt, dfl, off, doff, n in self._big])
         self._jac_count = len(descs)
         if descs:
             arr = (_JacobiDesc * len(descs))(*descs)
@@ -309,13 +315,12 @@ class KFACOptimizer(optim.Optimizer):
             rc = L.acktr_sym_eig_jacobi_batched_f32(_hip.dev_ptr(self._jac_descs, torch.uint8), self._jac_count,
                                                     self._jac_max, 1e-6, stream)
             _hip.check(rc, 'acktr_sym_eig_jacobi_batched_f32')
-        for run, qt, dfl, off, doff, n in self._big:
-            q = qt[off:off + n * n]
-            q.copy_(run[off:off + n * n])
-            rc = L.acktr_sym_eig_rocsolver_f32(_hip.dev_ptr(q), n, ctypes.c_void_p(dfl.data_ptr() + 4 * doff),
-                                               _hip.dev_ptr(self.e_work), _hip.dev_ptr(self.info, torch.int32), 1e-6,
-                                               stream)
-            _hip.check(rc, 'acktr_sym_eig_rocsolver_f32')
+        if self._big:
+            for run, qt, dfl, off, doff, n in self._big:        # syevd works in place: running average -> Q^T slot
+                qt[off:off + n * n].copy_(run[off:off + n * n])
+            rc = L.acktr_sym_eig_rocsolver_multi_f32(self._big_jobs, len(self._big), _hip.dev_ptr(self.e_work),
+                                                     _hip.dev_ptr(self.info, torch.int32), 1e-6, stream)
+            _hip.check(rc, 'acktr_sym_eig_rocsolver_multi_f32')
         if self.dp.active:
             # every factor was decomposed by exactly one rank: zero the slots this rank does not own and SUM
             # all-reduce the four flat buckets (= a broadcast from each owner in one collective per bucket)

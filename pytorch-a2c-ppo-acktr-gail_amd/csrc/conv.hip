@@ -173,11 +173,14 @@ int sw_num_cus() {
 
 // stationary-weight geometries (conv_sw.hpp): forward of the three layers, dgrad of layers 3 and 2
 // (channel counts are those of the reference's CNNBase, model.py:176-179; other counts take the tile-GEMM path)
-using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, 8, HM_KX>;
-using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, 8, HM_KY>;
-using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, 12, HM_CH>;
-using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 12, HM_CH>;    // padded 7x7 dY, flipped 3x3 kernel
-using SwD2 = SwGeom<2, 2, 1, 11, 11, 64, 4, 2, 8, HM_CH>;     // padded 9x9 dY, four 2x2 phase kernels stacked along M
+// (last parameter: threads per workgroup.  3-4 waves per SIMD were measured no faster than 2 except for the conv3
+//  dgrad: the kernels are paced by the MFMA pipe and the L1, and the smaller prefetch stages that fit the tighter
+//  register budget cost more than the extra waves hide)
+using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, 8, HM_KX, 512>;
+using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, 8, HM_KY, 512>;
+using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, 12, HM_CH, 512>;
+using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 12, HM_CH, 768>;    // padded 7x7 dY, flipped 3x3 kernel
+using SwD2 = SwGeom<2, 2, 1, 11, 11, 64, 4, 2, 8, HM_CH, 512>;     // padded 9x9 dY, four 2x2 phase kernels stacked along M
 
 static long sw_fwd_image_bytes(int geom, int C, int OC) {
     if (geom == GEOM_8S4 && SwF1::ok(C, OC)) return SwF1::lds_bytes();

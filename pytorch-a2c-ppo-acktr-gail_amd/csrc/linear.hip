@@ -99,26 +99,37 @@ int launch_slab_reduce(float* dst, const float* slabs, int nslabs, long n, long 
     return 0;
 }
 
-// Tile choice: 128x128 when it alone fills the chip, else 64x128 (twice the workgroups), skinny shapes get
-// 128x32 / 32x128.  256 CUs want a few hundred workgroups; split-K supplies the rest (see pick_slices).
-static int tile_rows_for(int M, int N) {
-    if (N <= 64) return 128;
-    if (M <= 32) return 32;
-    if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) return 128;
-    return 64;
+// Tile choice.  256 CUs want >= ~768 resident workgroups (3 waves per SIMD); LDS per workgroup sets how many fit:
+// 128x128 (74 KB, 2/CU) only when it alone fills the chip, 64x128 (55 KB, 2/CU) when it gives >= 256 tiles,
+// otherwise 64x64 (37 KB, 4/CU) -- the 1024x512x1568-class layers of this workload ran at < 1 wave per SIMD on
+// 64x128.  Skinny shapes get 128x32 / 32x128.  Split-K supplies the rest (see pick_slices).
+enum { TILE_128x32, TILE_32x128, TILE_64x64, TILE_64x128, TILE_128x128 };
+static int tile_cfg(int M, int N) {
+    if (N <= 64) return TILE_128x32;
+    if (M <= 32) return TILE_32x128;
+    if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) return TILE_128x128;
+    if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) return TILE_64x128;
+    return TILE_64x64;
 }
 template <class MOp, class NOp, class Epi>
 static int gemm_dispatch(const MOp& mop, const NOp& nop, const Epi& epi, int M, int N, int K, int nslices,
                          hipStream_t s) {
-    if (N <= 64) return launch_gemm<128, 32, 4, 1>(mop, nop, epi, M, N, K, nslices, s);
-    const int bm = tile_rows_for(M, N);
-    if (bm == 32) return launch_gemm<32, 128, 1, 4>(mop, nop, epi, M, N, K, nslices, s);
-    if (bm == 64) return launch_gemm<64, 128, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
-    return launch_gemm<128, 128, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
+    switch (tile_cfg(M, N)) {
+        case TILE_128x32: return launch_gemm<128, 32, 4, 1>(mop, nop, epi, M, N, K, nslices, s);
+        case TILE_32x128: return launch_gemm<32, 128, 1, 4>(mop, nop, epi, M, N, K, nslices, s);
+        case TILE_64x64: return launch_gemm<64, 64, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
+        case TILE_64x128: return launch_gemm<64, 128, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
+        default: return launch_gemm<128, 128, 2, 2>(mop, nop, epi, M, N, K, nslices, s);
+    }
 }
 long gemm_tiles(int M, int N) {
-    if (N <= 64) return (long)cdiv(M, 128) * cdiv(N, 32);
-    return (long)cdiv(M, tile_rows_for(M, N)) * cdiv(N, 128);
+    switch (tile_cfg(M, N)) {
+        case TILE_128x32: return (long)cdiv(M, 128) * cdiv(N, 32);
+        case TILE_32x128: return (long)cdiv(M, 32) * cdiv(N, 128);
+        case TILE_64x64: return (long)cdiv(M, 64) * cdiv(N, 64);
+        case TILE_64x128: return (long)cdiv(M, 64) * cdiv(N, 128);
+        default: return (long)cdiv(M, 128) * cdiv(N, 128);
+    }
 }
 
 // Generic C[M,N] (row major, ldc) = A(m,k) * B(n,k) with explicit element strides per operand:
@@ -173,7 +184,7 @@ using namespace acktr;
 static int fwd_slices(int B, int IN, int OUT, long ws_floats) {
     if (((long)B * OUT) % 4) return 1;
     long max_by_ws = ws_floats / ((long)B * OUT) - SLAB_GROUP_EXTRA;
-    long want = 512 / gemm_tiles(B, OUT);
+    long want = 768 / gemm_tiles(B, OUT);
     long by_k = IN / (8 * GK);                 // at least 8 K tiles per slice
     long n = want < by_k ? want : by_k;
     if (n > max_by_ws) n = max_by_ws;

@@ -9,6 +9,9 @@ namespace acktr {
 // Fixed-order slab reduction in float4 units.  One pass when there are few slabs; otherwise two passes:
 // pass 1 sums groups of slabs in parallel (grid.y = groups) into group partials, pass 2 sums the groups.
 // Both orders are fixed, so split-K results are run-to-run deterministic.
+// (Fusing the two passes into one launch -- last-arriving block sums the group partials behind an agent-scope
+//  fence + atomic ticket -- was measured 2x SLOWER per wgrad: on the 8-XCD part the release fence writes back the
+//  whole dirty L2, which at that moment holds megabytes of slabs.)
 // Epilogue (final pass only): v = scale*sum (+ bias[i % ncols]) -> act -> (+= dst).
 __global__ __launch_bounds__(256) void slab_reduce4_kernel(float* dst, const float* slabs, int first, int count,
                                                            long n4, long stride, float scale, int accumulate,

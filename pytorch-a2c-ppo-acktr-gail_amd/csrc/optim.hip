@@ -57,40 +57,65 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
                                                                   float* norm_out, const float* hyper_dev,
                                                                   const int* step_dev) {
     __shared__ float sm2[2];
+    __shared__ float sm_adam[2];
     float coef = 1.0f;
     if (hyper_dev) {
         const float lr = hyper_dev[0];
         eps = hyper_dev[3];
         if (MODE == 0) {
             beta1 = hyper_dev[1]; beta2 = hyper_dev[2];
-            const int t = *step_dev;
-            const double bc1 = 1.0 - pow((double)beta1, (double)t);     // torch/optim/adam.py:529-535 (host doubles there)
-            const double bc2 = 1.0 - pow((double)beta2, (double)t);
-            lr_or_step = (float)((double)lr / bc1);
-            bc2_sqrt = (float)sqrt(bc2);
+            // torch/optim/adam.py:529-535 evaluates these in host doubles; one lane per workgroup does (a double pow
+            // per lane cost more than the whole update), the rest read them from LDS
+            if (threadIdx.x == 0) {
+                const int t = *step_dev;
+                const double bc1 = 1.0 - pow((double)beta1, (double)t);
+                const double bc2 = 1.0 - pow((double)beta2, (double)t);
+                sm_adam[0] = (float)((double)lr / bc1);
+                sm_adam[1] = (float)sqrt(bc2);
+            }
+            __syncthreads();
+            lr_or_step = sm_adam[0];
+            bc2_sqrt = sm_adam[1];
         } else {
             beta2 = hyper_dev[1];
             lr_or_step = lr;
         }
     }
     if (use_clip) coef = clip_coef_from(partial, nparts, max_norm, sm2, norm_out);
-    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
-        float gi = g[i];
-        if (use_clip) { gi = gi * coef; g[i] = gi; }
+    auto upd = [&](float& pi, float& gi, float& a1, float& a2) {
+        if (use_clip) gi = gi * coef;
         if (MODE == 0) {
-            float m = s1[i], v = s2[i];
-            m = m + (1.0f - beta1) * (gi - m);                       // exp_avg.lerp_(grad, 1-beta1)
-            v = v * beta2 + (1.0f - beta2) * gi * gi;                // mul_(beta2).addcmul_(g, g, 1-beta2)
-            const float denom = sqrtf(v) / bc2_sqrt + eps;
-            p[i] = p[i] - lr_or_step * (m / denom);                  // addcdiv_(exp_avg, denom, -step_size)
-            s1[i] = m; s2[i] = v;
+            a1 = a1 + (1.0f - beta1) * (gi - a1);                    // exp_avg.lerp_(grad, 1-beta1)
+            a2 = a2 * beta2 + (1.0f - beta2) * gi * gi;              // mul_(beta2).addcmul_(g, g, 1-beta2)
+            const float denom = sqrtf(a2) / bc2_sqrt + eps;
+            pi = pi - lr_or_step * (a1 / denom);                     // addcdiv_(exp_avg, denom, -step_size)
         } else {
-            float sq = s1[i];
-            sq = sq * beta2 + (1.0f - beta2) * gi * gi;              // square_avg.mul_(alpha).addcmul_(g, g, 1-alpha)
-            const float avg = sqrtf(sq) + eps;
-            p[i] = p[i] - lr_or_step * (gi / avg);                   // addcdiv_(grad, avg, -lr)
-            s1[i] = sq;
+            a1 = a1 * beta2 + (1.0f - beta2) * gi * gi;              // square_avg.mul_(alpha).addcmul_(g, g, 1-alpha)
+            const float avg = sqrtf(a1) + eps;
+            pi = pi - lr_or_step * (gi / avg);                       // addcdiv_(grad, avg, -lr)
         }
+    };
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) == 0);
+    const long n4 = vec ? n / 4 : 0;
+    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * OPT_THREADS) {
+        v4 pv = reinterpret_cast<v4*>(p)[i], gv = reinterpret_cast<v4*>(g)[i], av = reinterpret_cast<v4*>(s1)[i];
+        v4 bv = av;
+        if (MODE == 0) bv = reinterpret_cast<v4*>(s2)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { float pj = pv[j], gj = gv[j], aj = av[j], bj = bv[j]; upd(pj, gj, aj, bj); pv[j] = pj; gv[j] = gj; av[j] = aj; bv[j] = bj; }
+        reinterpret_cast<v4*>(p)[i] = pv;
+        if (use_clip) reinterpret_cast<v4*>(g)[i] = gv;
+        reinterpret_cast<v4*>(s1)[i] = av;
+        if (MODE == 0) reinterpret_cast<v4*>(s2)[i] = bv;
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
+        float pi = p[i], gi = g[i], a1 = s1[i], a2 = MODE == 0 ? s2[i] : 0.f;
+        upd(pi, gi, a1, a2);
+        p[i] = pi;
+        if (use_clip) g[i] = gi;
+        s1[i] = a1;
+        if (MODE == 0) s2[i] = a2;
     }
 }
 

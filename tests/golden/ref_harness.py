@@ -34,12 +34,11 @@ def install():
         def __init__(self, *a, **k):
             pass
 
-    class RunningMeanStd(object):  # sb3 source is not in the container; unused by goldens
-        def __init__(self, epsilon=1e-4, shape=()):
-            import numpy as np
-            self.mean = np.zeros(shape, 'float64')
-            self.var = np.ones(shape, 'float64')
-            self.count = epsilon
+    # sb3 is not installed and its source is not in the container: the published algorithm restated in
+    # oracle/gail_ref.py stands in (predict_reward's normalisation is therefore "parity unpinned")
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+    from oracle.gail_ref import RunningMeanStd
 
     gym = _stub('gym', Wrapper=_Dummy, ObservationWrapper=_Dummy, Env=_Dummy)
     spaces = _stub('gym.spaces', Box=_Dummy)

@@ -179,3 +179,26 @@ def update_vector_errors(G, prefix_fmt, names, get_mine, get_truth):
         nt += np.sum(truth ** 2) / frac
     nt = max(nt, 1e-300)
     return np.sqrt(e_ref / nt), np.sqrt(e_mine / nt), np.sqrt(e_mg / nt)
+
+
+# ------------------------------------------------------------------------------------------ GAIL
+GAIL_CASES = [('hc', 17, 6, 100, 128, 8, 64), ('small', 11, 3, 64, 32, 5, 16)]     # tag, obs, act, hidden, batch, T, N
+
+
+def gail_inputs(ci):
+    """Discriminator parameters, a rollout and two fixed expert batches per update (mirrors make_golden_gail.py)."""
+    from oracle import gail_ref
+    tag, od, A, hid, B, T, N = GAIL_CASES[ci]
+    P = synth.make_params(gail_ref.disc_param_shapes(od + A, hid), 300 + ci)
+    ro = synth.make_rollouts(T, N, (od,), 'box', A, salt=700 + ci)
+    expert = [(synth.normalish((B, od), 710 + 10 * ci + k), synth.normalish((B, A), 715 + 10 * ci + k)) for k in range(2)]
+    return P, ro, expert
+
+
+def gail_expert_file_tensors(ci):
+    """A synthetic expert file in the gail_experts format (convert_to_pytorch.py:28-48): 6 trajectories x 60 steps."""
+    tag, od, A, hid, B, T, N = GAIL_CASES[ci]
+    nt, L = 6, 60
+    return OrderedDict([('states', t(synth.normalish((nt, L, od), 730 + ci))), ('actions', t(synth.normalish((nt, L, A), 731 + ci))),
+                        ('rewards', t(synth.normalish((nt, L), 732 + ci))),
+                        ('lengths', torch.tensor([60, 60, 40, 60, 20, 60], dtype=torch.int64))])

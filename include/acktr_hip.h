@@ -222,6 +222,35 @@ int acktr_kfac_precondition_f32(const float* grad, const float* qt_g, const floa
 int acktr_kfac_kl_clip_f32(const float* v, const float* g, long n, float lr, float kl_clip, float* out_vgsum_nu,
                            void* workspace, void* stream);
 
+/* ---- GAIL discriminator: the non-GEMM pieces of a2c_ppo_acktr/algo/gail.py ---------------- */
+
+/* gail.py:36-41,67-76: x_out[3B, Ds+Da] = rows [policy (s|a)] [expert (s|a)] [alpha*expert + (1-alpha)*policy]; alpha[B]. */
+int acktr_gail_mix_concat_f32(const float* policy_state, const float* policy_action, const float* expert_state,
+                              const float* expert_action, const float* alpha, int B, int Ds, int Da, float* x_out,
+                              void* stream);
+/* gail.py:78-85 on the trunk outputs d[3B] of those rows: loss_out[0] = BCE(expert, 1) + BCE(policy, 0) (means);
+ * seed[3B] = d loss / d d for the policy / expert rows and 1 for the mixup rows (the `ones` of gail.py:45);
+ * seed_bce[3B] = the same with 0 on the mixup rows. */
+int acktr_gail_bce_seed_f32(const float* d, int B, float* seed, float* seed_bce, float* loss_out, void* stream);
+/* gail.py:54: loss_out[1] = lambda * mean((||g_b|| - 1)^2) for g[B, D] = d D / d x at the mixup rows, and
+ * r[B, D] = d loss_out[1] / d g (the seed of the double backward).  row_scratch: B floats. */
+int acktr_gail_pen_seed_f32(const float* g, int B, int D, float lambda_, float* r, float* row_scratch, float* loss_out,
+                            void* stream);
+/* element-wise links of the (double) backward through tanh layers, h = tanh(.) stored, n elements, `cols` columns:
+ * mode 0: out0 = (1-h^2) in0;  1: out0 = (1-h^2) in0, out1 = in1*in0;  2: out0 = (1-h^2) in0,
+ * out1 = (1-h^2)(-2 h w[col] in0);  3: out0 = (1-h^2)(in0 - 2 h in1). */
+int acktr_gail_tanh_link_f32(int mode, const float* h, const float* in0, const float* in1, const float* w, long n,
+                             int cols, float* out0, float* out1, void* stream);
+/* gail.py:101-102: reward = log(sigmoid(d)) - log(1 - sigmoid(d)). */
+int acktr_gail_reward_f32(const float* d, long n, float* reward, void* stream);
+/* gail.py:107-108 for S consecutive steps of N environments (reward, masks: [S, N]): ret = ret*mask*gamma + reward per
+ * step (ret_io[N] carried in/out, every step's row in ret_steps[S, N]) and the per-step batch moments
+ * moments[S][2] = {mean, population variance} in fp64 that RunningMeanStd.update merges. */
+int acktr_gail_returns_moments_f32(const float* reward, const float* masks, int S, int N, float gamma, float* ret_io,
+                                   float* ret_steps, double* moments, void* stream);
+/* gail.py:110: reward[s, :] /= scale[s]. */
+int acktr_gail_scale_rows_f32(float* reward, const float* scale, int S, int N, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

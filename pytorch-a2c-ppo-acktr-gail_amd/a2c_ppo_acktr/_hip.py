@@ -81,6 +81,13 @@ _PROTOS = {
     'acktr_sym_eig_rocsolver_multi_f32': (c_i, [ctypes.POINTER(EigJob), c_i, c_p, c_p, c_f, c_p]),
     'acktr_kfac_precondition_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'acktr_kfac_kl_clip_f32': (c_i, [c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p]),
+    'acktr_gail_mix_concat_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
+    'acktr_gail_bce_seed_f32': (c_i, [c_p, c_i, c_p, c_p, c_p, c_p]),
+    'acktr_gail_pen_seed_f32': (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'acktr_gail_tanh_link_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p]),
+    'acktr_gail_reward_f32': (c_i, [c_p, c_l, c_p, c_p]),
+    'acktr_gail_returns_moments_f32': (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'acktr_gail_scale_rows_f32': (c_i, [c_p, c_p, c_i, c_i, c_p]),
 }
 
 

@@ -1,0 +1,289 @@
+"""GAIL discriminator and expert dataset -- host-side mirror of reference a2c_ppo_acktr/algo/gail.py.
+
+Same classes, constructor signatures, public attributes (`trunk`, `optimizer`, `returns`, `ret_rms`) and
+`state_dict` names as the reference; the arithmetic runs on the MI355X through the C-ABI (include/acktr_hip.h): the
+three linear layers on the GEMM / skinny kernels (forward, input gradients, weight gradients), everything else
+(minibatch assembly, BCE losses, gradient penalty and the element-wise links of its double backward, reward /
+running-return / moments) on the kernels of csrc/gail.hip.  There is no CPU path.
+
+Differences a caller can see: none in results (parity tests: tests/test_gail_gpu.py).  `predict_reward_batched`
+is an addition: all T steps of a rollout in one pass, same per-step semantics as T calls of `predict_reward`.
+"""
+import ctypes
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.utils.data
+
+from .. import _hip, ops
+from .ppo import _FlatAdam
+
+f32 = torch.float32
+
+
+class RunningMeanStd(object):
+    """stable_baselines3.common.running_mean_std.RunningMeanStd (gail.py:9,27): the published algorithm restated
+    (batch moments merged with Chan et al.'s parallel update, float64); sb3 itself is not a dependency here."""
+
+    def __init__(self, epsilon=1e-4, shape=()):
+        self.mean = np.zeros(shape, np.float64)
+        self.var = np.ones(shape, np.float64)
+        self.count = epsilon
+
+    def update(self, arr):
+        self.update_from_moments(np.mean(arr, axis=0), np.var(arr, axis=0), arr.shape[0])
+
+    def update_from_moments(self, batch_mean, batch_var, batch_count):
+        delta = batch_mean - self.mean
+        tot = self.count + batch_count
+        new_mean = self.mean + delta * batch_count / tot
+        m_2 = self.var * self.count + batch_var * batch_count + np.square(delta) * self.count * batch_count / tot
+        self.mean, self.var, self.count = new_mean, m_2 / tot, tot
+
+
+class Discriminator(nn.Module):
+    def __init__(self, input_dim, hidden_dim, device):
+        super(Discriminator, self).__init__()
+        self.device = device
+        # reference gail.py:17-20 (same modules, same default initialisation order -> same-seed weights)
+        self.trunk = nn.Sequential(
+            nn.Linear(input_dim, hidden_dim), nn.Tanh(),
+            nn.Linear(hidden_dim, hidden_dim), nn.Tanh(),
+            nn.Linear(hidden_dim, 1)).to(device)
+        self.trunk.train()
+        self._flatten()
+        # gail.py:24: torch.optim.Adam(self.trunk.parameters()) -- lr 1e-3, betas (.9, .999), eps 1e-8
+        self.optimizer = _FlatAdam(self, lr=1e-3, eps=1e-8)
+        self.returns = None
+        self.ret_rms = RunningMeanStd(shape=())
+        self._in, self._hid = input_dim, hidden_dim
+
+    # ------------------------------------------------------------------ flat parameter / gradient buffers
+    def _flatten(self):
+        ps = list(self.trunk.parameters())
+        dev = ps[0].device
+        offs, off = [], 0
+        for p in ps:
+            off = (off + 3) // 4 * 4
+            offs.append(off)
+            off += p.numel()
+        total = (off + 3) // 4 * 4
+        flat = torch.zeros(total, dtype=f32, device=dev)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self.__dict__['flat_params'] = flat
+        self.__dict__['flat_grads'] = torch.zeros_like(flat)
+        self.__dict__['_offs'] = offs
+
+    def _apply(self, fn, *a, **k):
+        r = super(Discriminator, self)._apply(fn, *a, **k)
+        self._flatten()
+        return r
+
+    def load_state_dict(self, *a, **k):
+        r = super(Discriminator, self).load_state_dict(*a, **k)   # copies in place: views stay bound
+        return r
+
+    def _gview(self, i):
+        p = list(self.trunk.parameters())[i]
+        o = self._offs[i]
+        return self.flat_grads[o:o + p.numel()].view(p.shape)
+
+    def _check_dev(self):
+        if not self.flat_params.is_cuda:
+            raise RuntimeError('Discriminator must live on the MI355X device; this package has no CPU path')
+
+    # ------------------------------------------------------------------ trunk forward (gail.py:17-20)
+    def _forward(self, x):
+        W1, b1, W2, b2, w3, b3 = list(self.trunk.parameters())
+        h1 = ops.linear_fwd(x, W1, b1, 'tanh')
+        h2 = ops.linear_fwd(h1, W2, b2, 'tanh')
+        d = ops.linear_fwd(h2, w3, b3, None)
+        return h1, h2, d
+
+    # ------------------------------------------------------------------ one minibatch: losses + all gradients
+    def _losses_and_grads(self, policy_state, policy_action, expert_state, expert_action, alpha, lambda_=10.0):
+        """gail.py:67-93 for one minibatch: returns a device tensor [gail_loss, grad_pen] and leaves
+        d(gail_loss + grad_pen)/d(parameters) in self.flat_grads."""
+        L = _hip.lib()
+        dev = self.flat_params.device
+        st = _hip.cur_stream(dev)
+        W1, b1, W2, b2, w3, b3 = list(self.trunk.parameters())
+        B, Ds, Da = policy_state.shape[0], policy_state.shape[1], policy_action.shape[1]
+        D, H = Ds + Da, W1.shape[0]
+        c = lambda t_: t_.to(device=dev, dtype=f32).contiguous()
+        ps, pa, es, ea, al = c(policy_state), c(policy_action), c(expert_state), c(expert_action), c(alpha).view(-1)
+        assert es.shape == (B, Ds) and ea.shape == (B, Da) and al.numel() == B, 'expert / policy batch shapes differ'
+        e = lambda *s: torch.empty(*s, dtype=f32, device=dev)
+        X = e(3 * B, D)
+        _hip.check(L.acktr_gail_mix_concat_f32(_hip.dev_ptr(ps), _hip.dev_ptr(pa), _hip.dev_ptr(es), _hip.dev_ptr(ea),
+                                               _hip.dev_ptr(al), B, Ds, Da, _hip.dev_ptr(X), st), 'acktr_gail_mix_concat_f32')
+        h1, h2, d = self._forward(X)                                   # all 3B rows at once
+        seed, seed_bce, loss = e(3 * B, 1), e(3 * B, 1), torch.zeros(2, dtype=f32, device=dev)
+        _hip.check(L.acktr_gail_bce_seed_f32(_hip.dev_ptr(d), B, _hip.dev_ptr(seed), _hip.dev_ptr(seed_bce),
+                                             _hip.dev_ptr(loss), st), 'acktr_gail_bce_seed_f32')
+        # first backward, all rows: policy / expert rows carry the BCE seeds, the mixup rows carry `ones` (gail.py:45-52)
+        a2 = ops.linear_dgrad(seed, w3, gate_src=h2, gate='tanh')       # rows<2B: d a2 (BCE); mixup rows: u2 = t2' * w3
+        v = ops.linear_dgrad(a2, W2)                                    # rows<2B: d h1 (BCE); mixup rows: v1
+        a1 = e(3 * B, H)
+        link = lambda mode, h, i0, i1, w, o0, o1: _hip.check(L.acktr_gail_tanh_link_f32(
+            mode, _hip.dev_ptr(h), _hip.dev_ptr(i0), _hip.dev_ptr(i1), _hip.dev_ptr(w), i0.numel(), H, _hip.dev_ptr(o0),
+            _hip.dev_ptr(o1), st), 'acktr_gail_tanh_link_f32')
+        link(0, h1, v, None, None, a1, None)                            # rows<2B: d a1 (BCE); mixup rows: u1 = t1' * v1
+        m = slice(2 * B, 3 * B)
+        u2, v1, u1, h1m, h2m = a2[m], v[m], a1[m], h1[m], h2[m]
+        g = ops.linear_dgrad(u1, W1)                                    # d D / d x at the mixup points  [B, D]
+        r, rows = e(B, D), e(B)
+        _hip.check(L.acktr_gail_pen_seed_f32(_hip.dev_ptr(g), B, D, float(lambda_), _hip.dev_ptr(r), _hip.dev_ptr(rows),
+                                             _hip.dev_ptr(loss), st), 'acktr_gail_pen_seed_f32')
+        # double backward (autograd of gail.py:46-54 through create_graph=True), mixup rows only
+        du1 = ops.linear_fwd(r, W1, None, None)                         # d u1 = r W1^T
+        dv1, dt1 = e(B, H), e(B, H)
+        link(1, h1m, du1, v1, None, dv1, dt1)
+        du2 = ops.linear_fwd(dv1, W2, None, None)                       # d u2 = d v1 W2^T
+        prod, da2p = e(B, H), e(B, H)
+        link(2, h2m, du2, None, w3.view(-1), prod, da2p)                # t2' * d u2 (-> d w3) and d a2 of the penalty
+        dh1p = ops.linear_dgrad(da2p, W2)
+        da1p = e(B, H)
+        link(3, h1m, dh1p, dt1, None, da1p, None)
+        # parameter gradients.  Weight gradients of the ordinary backward over all 3B rows (mixup rows replaced by the
+        # penalty's d a), then the two outer-product terms of the double backward added on top.
+        gW1, gb1, gW2, gb2, gw3, gb3 = [self._gview(i) for i in range(6)]
+        u2c, u1c = u2.clone(), u1.clone()                               # the rows are overwritten just below
+        a2[m].copy_(da2p)
+        a1[m].copy_(da1p)
+        ops.linear_wgrad(a1, X, gW1, gb1.view(-1))
+        ops.linear_wgrad(a2, h1, gW2, gb2.view(-1))
+        ops.linear_wgrad(seed_bce, h2, gw3, gb3.view(-1))
+        ops.gemm(u1c, r, out=gW1, trans_a=True, accumulate=True)        # d W1 += u1^T r
+        ops.gemm(u2c, dv1, out=gW2, trans_a=True, accumulate=True)      # d W2 += u2^T d v1
+        ones = torch.ones(B, 1, dtype=f32, device=dev)
+        ops.gemm(ones, prod, out=gw3, trans_a=True, accumulate=True)    # d w3 += sum_b t2' * d u2
+        return loss
+
+    # ------------------------------------------------------------------ reference API
+    def compute_grad_pen(self, expert_state, expert_action, policy_state, policy_action, lambda_=10):
+        """gail.py:29-55: the penalty value (a 0-d device tensor; no autograd graph -- use `update`)."""
+        self._check_dev()
+        alpha = torch.rand(expert_state.size(0), 1)                     # CPU default generator, like the reference
+        loss = self._losses_and_grads(policy_state, policy_action, expert_state, expert_action, alpha, lambda_)
+        return loss[1]
+
+    def update(self, expert_loader, rollouts, obsfilt=None):
+        """gail.py:57-95"""
+        self._check_dev()
+        self.train()
+        policy_data_generator = rollouts.feed_forward_generator(None, mini_batch_size=expert_loader.batch_size)
+        losses = []
+        for expert_batch, policy_batch in zip(expert_loader, policy_data_generator):
+            policy_state, policy_action = policy_batch[0], policy_batch[2]
+            expert_state, expert_action = expert_batch
+            expert_state = obsfilt(expert_state.numpy(), update=False)
+            expert_state = torch.FloatTensor(expert_state).to(self.device)
+            expert_action = expert_action.to(self.device)
+            alpha = torch.rand(expert_state.size(0), 1)                 # gail.py:35 (CPU RNG stream, F7)
+            loss = self._losses_and_grads(policy_state, policy_action, expert_state, expert_action, alpha)
+            losses.append(loss)
+            self.optimizer.step(max_grad_norm=None)                     # flat Adam; grads were just overwritten
+        tot = torch.stack(losses).sum(dim=1).cpu()                      # ONE host sync per update (the reference: one per batch)
+        return float(tot.double().sum().item()) / len(losses)
+
+    def _reward(self, state, action):
+        L = _hip.lib()
+        dev = self.flat_params.device
+        x = torch.cat([state.to(dev, f32), action.to(dev, f32)], dim=1).contiguous()
+        _, _, d = self._forward(x)
+        reward = torch.empty_like(d)
+        _hip.check(L.acktr_gail_reward_f32(_hip.dev_ptr(d), d.numel(), _hip.dev_ptr(reward), _hip.cur_stream(dev)),
+                   'acktr_gail_reward_f32')
+        return reward
+
+    def predict_reward(self, state, action, gamma, masks, update_rms=True):
+        """gail.py:97-110"""
+        self._check_dev()
+        with torch.no_grad():
+            self.eval()
+            reward = self._reward(state, action)
+            return self._normalise(reward.view(1, -1), masks.view(1, -1), gamma, update_rms).view(-1, 1)
+
+    def predict_reward_batched(self, states, actions, gamma, masks, update_rms=True):
+        """All steps of a rollout at once: states [T,N,Ds], actions [T,N,Da], masks [T,N,1] -> rewards [T,N,1], with
+        exactly the per-step semantics of T consecutive `predict_reward(states[t], actions[t], gamma, masks[t])` calls
+        (running return and RunningMeanStd updated step by step, step t scaled by the variance after step t)."""
+        self._check_dev()
+        with torch.no_grad():
+            self.eval()
+            T, N = states.shape[0], states.shape[1]
+            reward = self._reward(states.reshape(T * N, -1), actions.reshape(T * N, -1)).view(T, N)
+            return self._normalise(reward, masks.reshape(T, N), gamma, update_rms).view(T, N, 1)
+
+    def _normalise(self, reward, masks, gamma, update_rms):
+        L = _hip.lib()
+        dev = reward.device
+        S, N = reward.shape
+        if self.returns is None:
+            self.returns = reward[0].clone().view(-1, 1)
+        if not update_rms:
+            return reward / float(np.sqrt(self.ret_rms.var[0] + 1e-8))
+        masks = masks.to(dev, f32).contiguous()
+        ret_steps = torch.empty(S, N, dtype=f32, device=dev)
+        mom = torch.empty(S, 2, dtype=torch.float64, device=dev)
+        ret_io = self.returns.view(-1).contiguous()
+        _hip.check(L.acktr_gail_returns_moments_f32(_hip.dev_ptr(reward), _hip.dev_ptr(masks), S, N, float(gamma),
+                                                    _hip.dev_ptr(ret_io), _hip.dev_ptr(ret_steps),
+                                                    _hip.dev_ptr(mom, torch.float64), _hip.cur_stream(dev)),
+                   'acktr_gail_returns_moments_f32')
+        self.returns = ret_io.view(-1, 1)
+        mom_h = mom.cpu().numpy()                                       # S x {mean, var}: the sequential merge is scalar work
+        scale = np.empty(S, np.float32)
+        for s in range(S):
+            self.ret_rms.update_from_moments(mom_h[s, 0:1], mom_h[s, 1:2], N)
+            scale[s] = np.sqrt(self.ret_rms.var[0] + 1e-8)
+        out = reward.clone()
+        sc = torch.from_numpy(scale).to(dev)
+        _hip.check(L.acktr_gail_scale_rows_f32(_hip.dev_ptr(out), _hip.dev_ptr(sc), S, N, _hip.cur_stream(dev)),
+                   'acktr_gail_scale_rows_f32')
+        return out
+
+
+class ExpertDataset(torch.utils.data.Dataset):
+    """gail.py:113-166 -- the gail_experts on-disk format (gail_experts/convert_to_pytorch.py:28-48): a `torch.save`d
+    dict {'states' [B,T,Do] f32, 'actions' [B,T,Da] f32, 'rewards' [B,T] f32, 'lengths' [B] i64}."""
+
+    def __init__(self, file_name, num_trajectories=4, subsample_frequency=20):
+        all_trajectories = torch.load(file_name, weights_only=True)    # plain tensors only: nothing is executed from the file
+        for k in ('states', 'actions', 'rewards', 'lengths'):
+            if k not in all_trajectories:
+                raise KeyError('expert file %r lacks %r (gail_experts format)' % (file_name, k))
+        perm = torch.randperm(all_trajectories['states'].size(0))
+        idx = perm[:num_trajectories]
+        self.trajectories = {}
+        start_idx = torch.randint(0, subsample_frequency, size=(num_trajectories,)).long()
+        for k, v in all_trajectories.items():
+            data = v[idx]
+            if k != 'lengths':
+                self.trajectories[k] = torch.stack(
+                    [data[i, start_idx[i]::subsample_frequency] for i in range(num_trajectories)])
+            else:
+                self.trajectories[k] = data // subsample_frequency
+        self.i2traj_idx = {}
+        self.i2i = {}
+        self.length = self.trajectories['lengths'].sum().item()
+        lengths = [int(x) for x in self.trajectories['lengths']]
+        traj_idx, i = 0, 0
+        self.get_idx = []
+        for _ in range(self.length):
+            while lengths[traj_idx] <= i:
+                i -= lengths[traj_idx]
+                traj_idx += 1
+            self.get_idx.append((traj_idx, i))
+            i += 1
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, i):
+        traj_idx, i = self.get_idx[i]
+        return self.trajectories['states'][traj_idx][i], self.trajectories['actions'][traj_idx][i]

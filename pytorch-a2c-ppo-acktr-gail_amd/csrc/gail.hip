@@ -1,0 +1,226 @@
+// GAIL discriminator pieces that are not GEMMs (reference a2c_ppo_acktr/algo/gail.py):
+//   * minibatch assembly: [policy (s,a); expert (s,a); alpha-mixup] rows in one matrix          gail.py:36-41,67-76
+//   * BCE-with-logits losses and their backward seeds                                            gail.py:78-85
+//   * gradient penalty  lambda * mean((||d D/d x|| - 1)^2)  and its seed d pen / d g             gail.py:46-54
+//   * the element-wise links of the DOUBLE backward through the two tanh layers                  (autograd of gail.py:46-54,93)
+//   * predict_reward: log(sigmoid d) - log(1 - sigmoid d), the running discounted return,
+//     per-step batch moments for the RunningMeanStd merge, and the final scaling                 gail.py:97-110
+// The linear layers themselves (forward, input gradients, weight gradients) run on the MFMA GEMM / skinny kernels
+// of linear.hip; the host mirror (a2c_ppo_acktr/algo/gail.py) chains them.
+#include "common.hpp"
+#include "../../include/acktr_hip.h"
+
+#pragma clang fp contract(off)
+
+namespace acktr {
+
+// X[0:B] = [ps | pa], X[B:2B] = [es | ea], X[2B:3B] = alpha * expert + (1 - alpha) * policy
+__global__ __launch_bounds__(256) void gail_mix_concat_kernel(const float* ps, const float* pa, const float* es,
+                                                              const float* ea, const float* alpha, int B, int Ds, int Da,
+                                                              float* X) {
+    const int D = Ds + Da;
+    const long n = (long)B * D;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / D), c = (int)(i % D);
+        const float p = c < Ds ? ps[(long)b * Ds + c] : pa[(long)b * Da + (c - Ds)];
+        const float e = c < Ds ? es[(long)b * Ds + c] : ea[(long)b * Da + (c - Ds)];
+        const float a = alpha[b];
+        X[i] = p;
+        X[n + i] = e;
+        X[2 * n + i] = ((a) * (e)) + ((((1.0f) - (a))) * (p));            // alpha*expert + (1-alpha)*policy
+    }
+}
+
+// torch's binary_cross_entropy_with_logits: (1-y)*x + max(-x,0) + log(exp(-max(-x,0)) + exp(-x-max(-x,0)))
+__device__ __forceinline__ float bce_logits(float x, float y) {
+    const float mx = fmaxf(-x, 0.f);
+    return (1.f - y) * x + mx + logf(expf(-mx) + expf(-x - mx));
+}
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + expf(-x)); }
+
+// one workgroup: d[3B] -> seed[3B] (policy sigma/B, expert (sigma-1)/B, mixup 1), seed_bce[3B] (same, mixup 0),
+// loss_out[0] = mean bce(expert, 1) + mean bce(policy, 0)
+__global__ __launch_bounds__(256) void gail_bce_seed_kernel(const float* d, int B, float* seed, float* seed_bce,
+                                                            float* loss_out) {
+    __shared__ double sm[16];
+    double lp = 0.0, le = 0.0;
+    const float invB = 1.0f / (float)B;
+    for (int i = threadIdx.x; i < 3 * B; i += 256) {
+        const float x = d[i];
+        float s, sb;
+        if (i < B) { lp += (double)bce_logits(x, 0.f); s = sb = sigmoidf(x) * invB; }
+        else if (i < 2 * B) { le += (double)bce_logits(x, 1.f); s = sb = (sigmoidf(x) - 1.f) * invB; }
+        else { s = 1.f; sb = 0.f; }
+        seed[i] = s;
+        seed_bce[i] = sb;
+    }
+    lp = block_sum(lp, sm);
+    le = block_sum(le, sm);
+    if (threadIdx.x == 0) loss_out[0] = (float)(le / B) + (float)(lp / B);
+}
+
+// one wave per row: r = d pen / d g, pen partial; second stage below sums the row terms in order
+__global__ __launch_bounds__(256) void gail_pen_seed_kernel(const float* g, int B, int D, float lambda_, float* r,
+                                                            float* row_term) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B) return;
+    float ss = 0.f;
+    for (int c = lane; c < D; c += 64) { const float v = g[(long)row * D + c]; ss += v * v; }
+    ss = __shfl(wave_sum(ss), 0, 64);                 // wave_sum leaves the total in lane 0 only
+    const float nrm = sqrtf(ss);
+    const float dev = nrm - 1.f;
+    // d/dg [ lambda/B * (||g|| - 1)^2 ] = lambda/B * 2 (||g|| - 1) * g / ||g||   (0 at ||g|| = 0, like torch's norm backward)
+    const float k = nrm > 0.f ? lambda_ * 2.f * dev / ((float)B * nrm) : 0.f;
+    for (int c = lane; c < D; c += 64) r[(long)row * D + c] = k * g[(long)row * D + c];
+    if (lane == 0) row_term[row] = dev * dev;
+}
+__global__ __launch_bounds__(256) void gail_pen_sum_kernel(const float* row_term, int B, float lambda_, float* loss_out) {
+    __shared__ double sm[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += 256) s += (double)row_term[i];
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) loss_out[1] = lambda_ * (float)(s / B);
+}
+
+// element-wise links of the (double) backward through y = tanh(a), with h = tanh(a) stored:
+//   mode 0: out0 = (1 - h^2) * in0                                                       (tanh' gate)
+//   mode 1: out0 = (1 - h^2) * in0 ; out1 = in1 * in0              (d v1 and d t1' from d u1 (in0), v1 (in1))
+//   mode 2: out0 = (1 - h^2) * in0 ; out1 = (1 - h^2) * (-2 h * w[col] * in0)   (d w3 terms and d a2 from d u2 (in0))
+//   mode 3: out0 = (1 - h^2) * (in0 + (-2 h * in1))                           (d a1 from d h1 (in0) and d t1' (in1))
+__global__ __launch_bounds__(256) void gail_tanh_link_kernel(int mode, const float* h, const float* in0, const float* in1,
+                                                             const float* w, long n, int cols, float* out0, float* out1) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float hv = h[i], x = in0[i];
+        const float gate = 1.f - hv * hv;
+        if (mode == 0) {
+            out0[i] = gate * x;
+        } else if (mode == 1) {
+            out0[i] = gate * x;
+            out1[i] = in1[i] * x;
+        } else if (mode == 2) {
+            out0[i] = gate * x;
+            out1[i] = gate * (-2.f * hv * (w[i % cols] * x));
+        } else {
+            out0[i] = gate * (x + (-2.f * hv * in1[i]));
+        }
+    }
+}
+
+// reward = log(sigmoid d) - log(1 - sigmoid d)   (gail.py:101-102, evaluated like the reference, not as d itself)
+__global__ __launch_bounds__(256) void gail_reward_kernel(const float* d, long n, float* reward) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float s = sigmoidf(d[i]);
+        reward[i] = logf(s) - logf(1.f - s);
+    }
+}
+
+// running return over S consecutive steps of N environments: ret = ret*mask*gamma + reward (gail.py:107), one lane per env;
+// writes every step's returns row and keeps the last in `ret_io`
+__global__ __launch_bounds__(256) void gail_returns_kernel(const float* reward, const float* masks, int S, int N, float gamma,
+                                                           float* ret_io, float* ret_steps) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float r = ret_io[n];
+    for (int s = 0; s < S; ++s) {
+        r = ((((r) * (masks[(long)s * N + n]))) * (gamma)) + (reward[(long)s * N + n]);
+        ret_steps[(long)s * N + n] = r;
+    }
+    ret_io[n] = r;
+}
+
+// per-step batch moments in fp64 (numpy mean / var over the N environments): mom[s] = {mean, var}
+__global__ __launch_bounds__(256) void gail_step_moments_kernel(const float* ret_steps, int N, double* mom) {
+    __shared__ double sm[16];
+    const float* row = ret_steps + (long)blockIdx.x * N;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) s += (double)row[i];
+    s = block_sum(s, sm);
+    __shared__ double mean_s;
+    if (threadIdx.x == 0) mean_s = s / N;
+    __syncthreads();
+    const double mean = mean_s;
+    double v = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) { const double dlt = (double)row[i] - mean; v += dlt * dlt; }
+    v = block_sum(v, sm);
+    if (threadIdx.x == 0) { mom[2 * blockIdx.x] = mean; mom[2 * blockIdx.x + 1] = v / N; }
+}
+
+// reward[s, n] /= scale[s]
+__global__ __launch_bounds__(256) void gail_scale_rows_kernel(float* reward, const float* scale, int S, int N) {
+    const long n = (long)S * N;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) reward[i] = reward[i] / scale[i / N];
+}
+
+static int ew_grid(long n) {
+    long b = (n + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+}  // namespace acktr
+
+using namespace acktr;
+
+extern "C" int acktr_gail_mix_concat_f32(const float* policy_state, const float* policy_action, const float* expert_state,
+                                         const float* expert_action, const float* alpha, int B, int Ds, int Da, float* x_out,
+                                         void* stream) {
+    ACKTR_ARG(policy_state && policy_action && expert_state && expert_action && alpha && x_out, "gail_mix_concat: null pointer");
+    ACKTR_ARG(B > 0 && Ds > 0 && Da > 0, "gail_mix_concat: bad sizes");
+    hipLaunchKernelGGL(gail_mix_concat_kernel, dim3(ew_grid((long)B * (Ds + Da))), dim3(256), 0, (hipStream_t)stream,
+                       policy_state, policy_action, expert_state, expert_action, alpha, B, Ds, Da, x_out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_gail_bce_seed_f32(const float* d, int B, float* seed, float* seed_bce, float* loss_out, void* stream) {
+    ACKTR_ARG(d && seed && seed_bce && loss_out && B > 0, "gail_bce_seed: bad arguments");
+    hipLaunchKernelGGL(gail_bce_seed_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, d, B, seed, seed_bce, loss_out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_gail_pen_seed_f32(const float* g, int B, int D, float lambda_, float* r, float* row_scratch,
+                                       float* loss_out, void* stream) {
+    ACKTR_ARG(g && r && row_scratch && loss_out && B > 0 && D > 0, "gail_pen_seed: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gail_pen_seed_kernel, dim3(cdiv(B, 4)), dim3(256), 0, s, g, B, D, lambda_, r, row_scratch);
+    ACKTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gail_pen_sum_kernel, dim3(1), dim3(256), 0, s, row_scratch, B, lambda_, loss_out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_gail_tanh_link_f32(int mode, const float* h, const float* in0, const float* in1, const float* w, long n,
+                                        int cols, float* out0, float* out1, void* stream) {
+    ACKTR_ARG(mode >= 0 && mode <= 3 && h && in0 && out0 && n > 0 && cols > 0, "gail_tanh_link: bad arguments");
+    ACKTR_ARG((mode != 1 && mode != 3) || in1, "gail_tanh_link: mode %d needs in1", mode);
+    ACKTR_ARG((mode != 1 && mode != 2) || out1, "gail_tanh_link: mode %d needs out1", mode);
+    ACKTR_ARG(mode != 2 || w, "gail_tanh_link: mode 2 needs w");
+    hipLaunchKernelGGL(gail_tanh_link_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, mode, h, in0, in1, w, n, cols,
+                       out0, out1);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_gail_reward_f32(const float* d, long n, float* reward, void* stream) {
+    ACKTR_ARG(d && reward && n > 0, "gail_reward: bad arguments");
+    hipLaunchKernelGGL(gail_reward_kernel, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, d, n, reward);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_gail_returns_moments_f32(const float* reward, const float* masks, int S, int N, float gamma, float* ret_io,
+                                              float* ret_steps, double* moments, void* stream) {
+    ACKTR_ARG(reward && masks && ret_io && ret_steps && moments && S > 0 && N > 0, "gail_returns_moments: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(gail_returns_kernel, dim3(cdiv(N, 256)), dim3(256), 0, s, reward, masks, S, N, gamma, ret_io, ret_steps);
+    ACKTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(gail_step_moments_kernel, dim3(S), dim3(256), 0, s, ret_steps, N, moments);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_gail_scale_rows_f32(float* reward, const float* scale, int S, int N, void* stream) {
+    ACKTR_ARG(reward && scale && S > 0 && N > 0, "gail_scale_rows: bad arguments");
+    hipLaunchKernelGGL(gail_scale_rows_kernel, dim3(ew_grid((long)S * N)), dim3(256), 0, (hipStream_t)stream, reward, scale, S, N);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}

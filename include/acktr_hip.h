@@ -206,7 +206,8 @@ int acktr_sym_eig_jacobi_batched_f32(const void* descs_dev, int count, int max_n
 int acktr_sym_eig_rocsolver_f32(float* a_inout_qt, int n, float* d, float* e_work, int* info_dev, float thresh,
                                 void* stream);
 /* The same for `count` (<= 64) factors at once (`jobs` is a HOST array): the solves -- latency-bound chains of small
- * kernels -- run concurrently on internal side streams that fork from / join into `stream`.  e_work: sum of all n
+ * kernels -- run concurrently on internal side streams that fork from `stream`; the call returns after the side
+ * streams have drained (host join), so work enqueued on `stream` afterwards sees the results.  e_work: sum of all n
  * floats, info_dev: count ints.  One device per process. */
 typedef struct acktr_eig_job { float* a_inout_qt; float* d; int n; int reserved; } acktr_eig_job;
 int acktr_sym_eig_rocsolver_multi_f32(const acktr_eig_job* jobs, int count, float* e_work, int* info_dev, float thresh,

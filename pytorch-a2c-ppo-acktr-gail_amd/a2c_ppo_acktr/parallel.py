@@ -19,6 +19,10 @@ class DataParallel(object):
             self.rank = dist.get_rank(group)
         else:
             self.world, self.rank = 1, 0
+        # gloo is a host transport: device buckets are staged through host memory here, synchronously, instead of
+        # through gloo's own device path (which was seen to hang when two ranks share one GPU, the only way a one-GPU
+        # box can rehearse world_size 2).  RCCL ("nccl") reduces the device bucket in place, stream-ordered.
+        self._host_staged = self.world > 1 and dist.get_backend(group) == 'gloo'
 
     @property
     def active(self):
@@ -38,12 +42,22 @@ class DataParallel(object):
     def all_reduce_sum_(self, flat):
         """In-place SUM all-reduce of one flat bucket (gradients, KFAC factors, loss accumulators)."""
         if self.active:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self._host_staged and flat.is_cuda:
+                host = flat.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                flat.copy_(host)
+            else:
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
     def broadcast_(self, t, src):
         if self.active:
-            dist.broadcast(t, src=src, group=self.group)
+            if self._host_staged and t.is_cuda:
+                host = t.cpu()
+                dist.broadcast(host, src=src, group=self.group)
+                t.copy_(host)
+            else:
+                dist.broadcast(t, src=src, group=self.group)
         return t
 
 

@@ -366,10 +366,13 @@ extern "C" int acktr_sym_eig_rocsolver_f32(float* a_inout_qt, int n, float* d, f
 
 // Several syevd problems at once.  Each solve is a long chain of small, latency-bound kernels (31 ms at n = 1569,
 // 11 ms at n = 513 on MI355X) that leaves the chip nearly idle, so the solves are spread over side streams
-// (longest first) that fork from and join back into the caller's stream with events.
+// (longest first) that fork from the caller's stream with an event; every worker thread drains its own stream before
+// it returns, so the join is on the host.  (An event join back into the caller's stream was measured to deadlock
+// against a collective library's own record-on-current-stream / wait-on-pool-stream pattern when the caller's
+// stream is the null stream; the host join costs nothing here because syevd's host driver blocks anyway.)
 namespace acktr {
 constexpr int EIG_STREAMS = 4;
-struct EigSide { hipStream_t s; rocblas_handle h; hipEvent_t done; };
+struct EigSide { hipStream_t s; rocblas_handle h; };
 static EigSide g_side[EIG_STREAMS];
 static hipEvent_t g_fork = nullptr;
 static int g_side_dev = -1;
@@ -381,7 +384,6 @@ static int ensure_side_streams() {
     if (hipEventCreateWithFlags(&g_fork, hipEventDisableTiming) != hipSuccess) { set_error("hipEventCreate failed"); return -1; }
     for (int i = 0; i < EIG_STREAMS; ++i) {
         if (hipStreamCreateWithFlags(&g_side[i].s, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&g_side[i].done, hipEventDisableTiming) != hipSuccess ||
             rocblas_create_handle(&g_side[i].h) != rocblas_status_success ||
             rocblas_set_stream(g_side[i].h, g_side[i].s) != rocblas_status_success) {
             set_error("sym_eig_rocsolver_multi: could not create side stream %d", i);
@@ -444,20 +446,13 @@ extern "C" int acktr_sym_eig_rocsolver_multi_f32(const acktr_eig_job* jobs, int 
                 hipLaunchKernelGGL(eig_threshold_kernel, dim3(cdiv(jb.n, 256)), dim3(256), 0, sd.s, jb.d, jb.n, thresh);
                 if (hipGetLastError() != hipSuccess) { status[i] = -3; failed_n[i] = jb.n; return; }
             }
+            if (hipStreamSynchronize(sd.s) != hipSuccess) status[i] = -4;
         });
     }
     for (int i = 0; i < EIG_STREAMS; ++i) if (used[i]) workers[i].join();
     for (int i = 0; i < EIG_STREAMS; ++i) {
         if (used[i] && status[i] != 0) {
             set_error("sym_eig_rocsolver_multi: solve (n=%d) on side stream %d failed with status %d", failed_n[i], i, status[i]);
-            return -1;
-        }
-    }
-    for (int i = 0; i < EIG_STREAMS; ++i) {
-        if (!used[i]) continue;
-        if (hipEventRecord(g_side[i].done, g_side[i].s) != hipSuccess ||
-            hipStreamWaitEvent(main_s, g_side[i].done, 0) != hipSuccess) {
-            set_error("sym_eig_rocsolver_multi: join failed");
             return -1;
         }
     }

@@ -1,0 +1,83 @@
+"""The data-parallel update path END TO END on the HIP kernels: 2 ranks (both on cuda:0, `gloo` process group -- RCCL
+refuses two ranks on one device) run PPO.update / A2C_ACKTR(acktr).update on their shards of every minibatch and must
+end with the parameters of the single-process update on the full minibatches (same seeds).  Covers what the 8-GPU
+bench relies on: index sharding through the fused gather, 1/B_global loss scaling, the flat-bucket all-reduce between
+the captured forward/backward and optimiser graphs, factor all-reduce and sharded eigendecompositions."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir, algo_name):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), 'pytorch-a2c-ppo-acktr-gail_amd'), here,
+              os.path.join(here, 'golden')):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import synth
+    from helpers import t
+    from test_policy_gpu import Discrete, make_storage
+    import datetime
+    if world > 1:
+        os.environ['MASTER_ADDR'] = '127.0.0.1'
+        os.environ['MASTER_PORT'] = str(port)
+        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    torch.cuda.set_device(0)
+    from a2c_ppo_acktr import algo
+    from a2c_ppo_acktr.model import Policy
+    T, N, A = 6, 12, 6                                   # 72 samples: minibatches of 36 -> shards of 18
+    torch.manual_seed(3)
+    pol = Policy((4, 84, 84), Discrete(A))
+    pol.to('cuda')
+    ro = synth.make_rollouts(T, N, (4, 84, 84), 'discrete', A, salt=610)
+    rs = make_storage(ro, (4, 84, 84), Discrete(A))
+    if algo_name == 'ppo':
+        rs.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
+        agent = algo.PPO(pol, clip_param=0.1, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01,
+                         lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
+        n_upd = 3                                        # the third update replays the captured graphs
+    else:
+        rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
+        agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
+        agent.optimizer.Tf = 2
+        n_upd = 3
+    losses = []
+    for it in range(n_upd):
+        torch.manual_seed(40 + it)                       # same CPU stream on every rank: permutation and Fisher noise
+        losses.append(agent.update(rs))
+        print('[dp test] %s world %d rank %d update %d done' % (algo_name, world, rank, it), flush=True)
+    torch.cuda.synchronize()
+    if rank == 0:
+        torch.save({'flat': pol.flat_params.detach().cpu(), 'losses': torch.tensor(losses, dtype=torch.float64)},
+                   os.path.join(out_dir, '%s_w%d.pt' % (algo_name, world)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr'])
+def test_two_rank_update_matches_single_process(tmp_path, algo_name):
+    out = str(tmp_path)
+    mp.spawn(_worker, args=(1, 0, out, algo_name), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, algo_name), nprocs=2, join=True)
+    one = torch.load(os.path.join(out, '%s_w1.pt' % algo_name))
+    two = torch.load(os.path.join(out, '%s_w2.pt' % algo_name))
+    np.testing.assert_allclose(two['losses'].numpy(), one['losses'].numpy(), rtol=2e-4, atol=1e-6)
+    err = float((two['flat'] - one['flat']).norm() / one['flat'].norm())
+    assert err < (2e-5 if algo_name == 'ppo' else 1e-3), err

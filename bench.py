@@ -37,6 +37,11 @@ class Discrete(object):
         self.n = n
 
 
+class Box(object):
+    def __init__(self, dim):
+        self.shape = (dim,)
+
+
 def synth_rollouts(T, N, device, seed):
     """SURVEY.md 8(d) synthetic inputs, generated on `device` from a fixed seed (identical on every rank)."""
     g = torch.Generator(device=device).manual_seed(seed)
@@ -73,9 +78,9 @@ def fill_storage(ro, device):
     return rs
 
 
-def cpu_baseline(ro_cpu, seed):
+def cpu_baseline(ro_cpu, seed, max_updates=12, budget_s=12.0):
     """The oracle (CPU restatement of the reference's PPO.update, torch CPU ops) on the per-GPU workload:
-    ONE full update of T=128 x 32 processes, 4 epochs x 4 minibatches (bounded sample, ~10-30 s)."""
+    full updates of T=128 x 32 processes, 4 epochs x 4 minibatches (bounded sample, ~10-30 s)."""
     from collections import OrderedDict
     from oracle import algo_ref, returns_ref
     from a2c_ppo_acktr.model import Policy
@@ -92,7 +97,7 @@ def cpu_baseline(ro_cpu, seed):
     T, N = ro['rewards'].shape[:2]
     t0 = time.perf_counter()
     n_upd, losses = 0, None
-    while n_upd < 12 and (n_upd == 0 or time.perf_counter() - t0 < 12.0):      # bounded sample: ~12 s of host work
+    while n_upd < max_updates and (n_upd == 0 or time.perf_counter() - t0 < budget_s):   # bounded sample of host work
         losses = algo_ref.ppo_update(P, opt, ro, **PPO_HP)
         n_upd += 1
     dt = time.perf_counter() - t0
@@ -190,6 +195,85 @@ def side_metrics(device):
         out['gae_scan_%dx%d' % (T, N)] = dict(ms=round(ms1, 4), algorithmic_bytes=T * N * 20,
                                               gbps=round(T * N * 20 / (ms1 * 1e-3) / 1e9, 1), hbm_peak_gbps=8000)
         del rs
+    # ---- configs[0]: PPO on the Hopper-shaped MLP (obs 11, act 3, T=2048, N=1, 10 epochs x 32 minibatches of 64):
+    # launch/latency bound -> microseconds per minibatch step
+    T, N = 2048, 1
+    g = torch.Generator(device=device).manual_seed(24)
+    torch.manual_seed(10)
+    pol = Policy((11,), Box(3)); pol.to(device)
+    agent = algo.PPO(pol, 0.2, 10, 32, 0.5, 0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)
+    rs = RolloutStorage(1, 1, (1,), Box(3), 1)
+    rs.num_steps = T
+    rs.obs = torch.randn(T + 1, N, 11, device=device, generator=g)
+    rs.actions = torch.randn(T, N, 3, device=device, generator=g)
+    rs.rewards = torch.randn(T, N, 1, device=device, generator=g)
+    rs.value_preds = torch.randn(T + 1, N, 1, device=device, generator=g)
+    rs.action_log_probs = 0.1 * torch.randn(T, N, 1, device=device, generator=g) - 2
+    rs.masks = (torch.rand(T + 1, N, 1, device=device, generator=g) < 0.99).float()
+    rs.bad_masks = (torch.rand(T + 1, N, 1, device=device, generator=g) < 0.995).float()
+    rs.returns = torch.zeros(T + 1, N, 1, device=device)
+    rs.recurrent_hidden_states = torch.zeros(T + 1, N, 1, device=device)
+    rs.compute_returns(torch.randn(N, 1, device=device, generator=g), True, 0.99, 0.95, True)
+    _timed_updates(agent, rs, 2, 600)
+    ms = _timed_updates(agent, rs, 10, 610)
+    med = statistics.median(ms)
+    out['ppo_mlp_update'] = dict(workload='PPO.update MLPBase obs 11 / DiagGaussian(3), T=2048 x 1 proc, 10 epochs x 32 '
+                                          'minibatches of 64 (configs[0])',
+                                 ms_median=round(med, 3), us_per_minibatch_step=round(med * 1e3 / 320, 2),
+                                 samples_per_s=round(T * N * 10 / (med * 1e-3), 1))
+    del rs, agent, pol
+    # ---- configs[4]: GAIL on HalfCheetah-shaped data (obs 17, act 6, T=2048 x 1024 procs): discriminator rewards for the
+    # whole rollout in one batched call, and the discriminator update against a synthetic gail_experts-format file
+    import tempfile
+    from a2c_ppo_acktr.algo import gail
+    T, N, Ds, Da = 2048, 1024, 17, 6
+    g = torch.Generator(device=device).manual_seed(25)
+    torch.manual_seed(11)
+    disc = gail.Discriminator(Ds + Da, 100, device)
+    rs = RolloutStorage(1, 1, (1,), Box(Da), 1)
+    rs.num_steps = T
+    rs.obs = torch.randn(T + 1, N, Ds, device=device, generator=g)
+    rs.actions = torch.randn(T, N, Da, device=device, generator=g)
+    rs.rewards = torch.zeros(T, N, 1, device=device)
+    rs.value_preds = torch.zeros(T + 1, N, 1, device=device)
+    rs.action_log_probs = torch.zeros(T, N, 1, device=device)
+    rs.masks = (torch.rand(T + 1, N, 1, device=device, generator=g) < 0.99).float()
+    rs.bad_masks = torch.ones(T + 1, N, 1, device=device)
+    rs.returns = torch.zeros(T + 1, N, 1, device=device)
+    rs.recurrent_hidden_states = torch.zeros(T + 1, N, 1, device=device)
+    pr = []
+    for i in range(4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rs.rewards.copy_(disc.predict_reward_batched(rs.obs[:-1], rs.actions, 0.99, rs.masks[:-1]))
+        torch.cuda.synchronize()
+        pr.append((time.perf_counter() - t0) * 1e3)
+    with tempfile.TemporaryDirectory() as td:
+        gcpu = torch.Generator().manual_seed(26)
+        fn = os.path.join(td, 'trajs_synthetic.pt')
+        torch.save({'states': torch.randn(64, 1000, Ds, generator=gcpu), 'actions': torch.randn(64, 1000, Da, generator=gcpu),
+                    'rewards': torch.randn(64, 1000, generator=gcpu), 'lengths': torch.full((64,), 1000, dtype=torch.int64)}, fn)
+        res = {}
+        for ntraj in (4, 64):                       # 4 = main.py's default (one batch of 128 per update); 64 -> 25 batches
+            torch.manual_seed(12)
+            ds = gail.ExpertDataset(fn, num_trajectories=ntraj, subsample_frequency=20)
+            loader = torch.utils.data.DataLoader(ds, batch_size=128, shuffle=True, drop_last=True)
+            obsfilt = lambda x, update=False: x
+            ms = []
+            for i in range(6):
+                torch.manual_seed(700 + i)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                disc.update(loader, rs, obsfilt)
+                torch.cuda.synchronize()
+                ms.append((time.perf_counter() - t0) * 1e3)
+            res[ntraj] = (statistics.median(ms[2:]), len(loader))
+    out['gail'] = dict(workload='GAIL Discriminator 23->100->100->1 (configs[4]: obs 17, act 6, T=2048 x 1024 procs, batch 128)',
+                       predict_reward_rollout_ms=round(min(pr[1:]), 3),
+                       predict_reward_samples_per_s=round(T * N / (min(pr[1:]) * 1e-3), 1),
+                       update_ms_4_trajectories=round(res[4][0], 3), update_batches_4_trajectories=res[4][1],
+                       update_ms_64_trajectories=round(res[64][0], 3), update_batches_64_trajectories=res[64][1],
+                       us_per_discriminator_step=round(res[64][0] * 1e3 / res[64][1], 1))
     return out
 
 
@@ -284,7 +368,7 @@ def main():
                    whole_update=dict(mfma_tflops=round(samples_per_step * args.steps * FWD_BWD_FLOP_PER_SAMPLE / dt / 1e12 / world, 2),
                                      frac_of_f32_mfma_peak=round(samples_per_step * args.steps * FWD_BWD_FLOP_PER_SAMPLE / dt / 1e12 / world
                                                                  / MFMA_F32_PEAK_TFLOPS, 4),
-                                     gemm_ops_ms_per_step=round(gemm_ms / args.steps, 3),
+                                     gemm_ops_ms_per_update=round(gemm_ms, 3),
                                      gemm_ops_tflops=round(gemm_flop / (gemm_ms * 1e-3) / 1e12, 2) if gemm_ms else None),
                    kernels={k: dict(calls=v['calls'], avg_ms=round(v['avg_ms'], 4),
                                     tflops=round(v['flops_per_call'] / (v['avg_ms'] * 1e-3) / 1e12, 2))
@@ -297,12 +381,18 @@ def main():
                 out['side_metrics'] = side_metrics(device)
             except Exception as e:                       # never lose the headline line over a side figure
                 out['side_metrics'] = dict(error=repr(e))
-        if not args.no_cpu_baseline:
-            keep = {k: v[:, :PROCS_PER_GPU].cpu() if v.dim() == 3 or v.dim() == 5 else v[:PROCS_PER_GPU].cpu()
-                    for k, v in ro.items()}
+        if world == 1 and not args.no_cpu_baseline:
+            keep = {k: v.cpu() for k, v in ro.items()}
             cb, _ = cpu_baseline(keep, seed=7)
             cb['value'] = round(cb['value'], 1)
             out['cpu_baseline'] = cb
+            # the reference itself runs single-threaded (main.py:38 torch.set_num_threads(1)): one update that way too
+            nthr = torch.get_num_threads()
+            torch.set_num_threads(1)
+            cb1, _ = cpu_baseline(keep, seed=7, max_updates=1)
+            torch.set_num_threads(nthr)
+            cb1['value'] = round(cb1['value'], 1)
+            out['cpu_baseline_1thread'] = cb1
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

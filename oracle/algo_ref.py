@@ -47,6 +47,29 @@ def gather_minibatch(ro, indices, advantages):
     return obs, actions, vp, ret, old_lp, adv
 
 
+def recurrent_env_batches(num_processes, num_mini_batch):
+    """storage.py:146-153: one randperm over ENVS per call; consecutive groups of N // num_mini_batch envs."""
+    assert num_processes >= num_mini_batch
+    per = num_processes // num_mini_batch
+    perm = torch.randperm(num_processes)
+    return [perm[s:s + per] for s in range(0, num_processes, per)]
+
+
+def gather_recurrent(ro, envs, advantages):
+    """storage.py:154-202: whole trajectories of the chosen envs, flattened to row t*Nb + j."""
+    envs = torch.as_tensor(envs, dtype=torch.long)
+    flat = lambda t: t.reshape(-1, *t.shape[2:])
+    obs = flat(ro['obs'][:-1][:, envs])
+    hxs = ro['recurrent_hidden_states'][0, envs]
+    actions = flat(ro['actions'][:, envs])
+    vp = flat(ro['value_preds'][:-1][:, envs])
+    ret = flat(ro['returns'][:-1][:, envs])
+    masks = flat(ro['masks'][:-1][:, envs])
+    old_lp = flat(ro['action_log_probs'][:, envs])
+    adv = flat(advantages[:, envs])
+    return obs, hxs, actions, vp, ret, masks, old_lp, adv
+
+
 # --------------------------------------------------------------------------
 # optimiser pieces
 # --------------------------------------------------------------------------
@@ -127,11 +150,11 @@ def _grads(P, loss):
 
 def ppo_minibatch_grads(P, obs, actions, old_values, returns, old_logp, adv,
                         clip_param, value_loss_coef, entropy_coef,
-                        use_clipped_value_loss=True):
+                        use_clipped_value_loss=True, rnn_hxs=None, masks=None):
     """One forward+backward of ppo.py:57-81; returns (losses triple, grads dict)."""
     for v in P.values():
         v.requires_grad_(True)
-    values, logp, ent = policy_ref.evaluate_actions(P, obs, actions)
+    values, logp, ent = policy_ref.evaluate_actions(P, obs, actions, rnn_hxs, masks)
     vl, al, en = ppo_losses(values, logp, ent, old_values, returns, old_logp, adv,
                             clip_param, use_clipped_value_loss)
     G = _grads(P, vl * value_loss_coef + al - en * entropy_coef)
@@ -145,11 +168,18 @@ def ppo_update(P, opt, ro, clip_param, ppo_epoch, num_mini_batch, value_loss_coe
     T, N = ro['rewards'].shape[:2]
     sums = [0.0, 0.0, 0.0]
     for _ in range(ppo_epoch):
-        for idx in minibatch_indices(T * N, num_mini_batch):
-            obs, act, vp, ret, olp, a = gather_minibatch(ro, idx, adv)
+        if policy_ref.is_recurrent(P):                                  # ppo.py:44-46
+            batches = [gather_recurrent(ro, envs, adv) for envs in recurrent_env_batches(N, num_mini_batch)]
+        else:
+            batches = [gather_minibatch(ro, idx, adv) for idx in minibatch_indices(T * N, num_mini_batch)]
+        for b in batches:
+            if policy_ref.is_recurrent(P):
+                obs, hxs, act, vp, ret, masks, olp, a = b
+            else:
+                (obs, act, vp, ret, olp, a), hxs, masks = b, None, None
             losses, G = ppo_minibatch_grads(P, obs, act, vp, ret, olp, a, clip_param,
                                             value_loss_coef, entropy_coef,
-                                            use_clipped_value_loss)
+                                            use_clipped_value_loss, hxs, masks)
             clip_grad_norm_(list(G.values()), max_grad_norm)
             adam_step(P, G, opt, lr, eps)
             for i in range(3):
@@ -165,7 +195,11 @@ def a2c_grads(P, ro, value_loss_coef, entropy_coef):
     T, N = ro['rewards'].shape[:2]
     obs = ro['obs'][:-1].reshape(T * N, *ro['obs'].shape[2:])
     act = ro['actions'].reshape(T * N, -1)
-    values, logp, ent = policy_ref.evaluate_actions(P, obs, act)
+    hxs = masks = None
+    if policy_ref.is_recurrent(P):                                      # a2c_acktr.py:38-43
+        hxs = ro['recurrent_hidden_states'][0]
+        masks = ro['masks'][:-1].reshape(T * N, 1)
+    values, logp, ent = policy_ref.evaluate_actions(P, obs, act, hxs, masks)
     values = values.view(T, N, 1)
     logp = logp.view(T, N, 1)
     adv = ro['returns'][:-1] - values

@@ -51,7 +51,7 @@ def randint(shape, salt, hi):
     return (hash_u32(n, salt) % np.uint64(hi)).astype(np.int64).reshape(shape)
 
 
-def make_rollouts(T, N, obs_shape, action_kind, A, salt, p_mask=0.97, p_bad=0.98):
+def make_rollouts(T, N, obs_shape, action_kind, A, salt, p_mask=0.97, p_bad=0.98, hidden=None):
     """Synthetic rollout of the shapes in SURVEY.md 8(d).
 
     action_kind 'discrete' -> int64 actions [T,N,1] in [0,A); 'box' -> fp32 [T,N,A].
@@ -73,6 +73,8 @@ def make_rollouts(T, N, obs_shape, action_kind, A, salt, p_mask=0.97, p_bad=0.98
     ro['masks'] = bernoulli((T + 1, N, 1), salt + 6, p_mask)
     ro['bad_masks'] = bernoulli((T + 1, N, 1), salt + 7, p_bad)
     ro['next_value'] = normalish((N, 1), salt + 8)
+    if hidden is not None:                       # recurrent policies: stored GRU states in (-1, 1) like real ones
+        ro['recurrent_hidden_states'] = uniform((T + 1, N, hidden), salt + 9, -0.9, 0.9)
     return ro
 
 
@@ -83,7 +85,7 @@ def make_params(shapes, salt, head_gain=0.5):
         s = salt * 131 + j
         if name.endswith('logstd._bias'):
             P[name] = uniform(shp, s, -0.5, 0.5)
-        elif name.endswith('bias'):
+        elif name.endswith('bias') or '.bias_' in name:          # incl. nn.GRU's bias_ih_l0 / bias_hh_l0
             P[name] = uniform(shp, s, -0.1, 0.1)
         else:
             fan_in = int(np.prod(shp[1:]))

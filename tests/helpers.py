@@ -202,3 +202,37 @@ def gail_expert_file_tensors(ci):
     return OrderedDict([('states', t(synth.normalish((nt, L, od), 730 + ci))), ('actions', t(synth.normalish((nt, L, A), 731 + ci))),
                         ('rewards', t(synth.normalish((nt, L), 732 + ci))),
                         ('lengths', torch.tensor([60, 60, 40, 60, 20, 60], dtype=torch.int64))])
+
+
+# ------------------------------------------------------------------------------------------ recurrent path
+# mirrors tests/golden/make_golden_rec.py
+REC_EVAL_CASES = [('mlp', 'mlp', 11, 3, 6, 4), ('cnn', 'cnn', None, 6, 5, 3)]
+REC_PPO_CASES = [('mlp', 'mlp', 11, 3, 8, 4, dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5,
+                                                   entropy_coef=0.0, lr=3e-4, eps=1e-5, max_grad_norm=0.5)),
+                 ('cnn', 'cnn', None, 6, 6, 4, dict(clip_param=0.1, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5,
+                                                    entropy_coef=0.01, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5))]
+REC_A2C_CASES = [('cnn', 'cnn', None, 6, 5, 4), ('mlp', 'mlp', 17, 6, 5, 8)]
+
+
+def rec_shapes_for(kind, od, A):
+    from oracle import policy_ref
+    if kind == 'cnn':
+        return policy_ref.cnn_param_shapes(4, 512, A, recurrent=True)
+    return policy_ref.mlp_param_shapes(od, 64, A, recurrent=True)
+
+
+def rec_rollouts(kind, od, A, T, N, salt):
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    return synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=salt, p_mask=0.8,
+                               hidden=512 if kind == 'cnn' else 64)
+
+
+def rec_eval_inputs(ci):
+    """numpy inputs of golden group rec/eval_* (obs, act, hxs, masks, vp, ret, adv) plus the raw rollout."""
+    tag, kind, od, A, T, N = REC_EVAL_CASES[ci]
+    ro = rec_rollouts(kind, od, A, T, N, 1900 + ci)
+    B = T * N
+    return dict(obs=ro['obs'][:-1].reshape((B,) + ro['obs'].shape[2:]), act=ro['actions'].reshape(B, -1),
+                hxs=ro['recurrent_hidden_states'][0], masks=ro['masks'][:-1].reshape(B, 1),
+                vp=ro['value_preds'][:-1].reshape(B, 1), ret=synth.normalish((B, 1), 1950 + ci),
+                adv=synth.normalish((B, 1), 1960 + ci)), ro

@@ -252,6 +252,20 @@ int acktr_gail_returns_moments_f32(const float* reward, const float* masks, int 
 /* gail.py:110: reward[s, :] /= scale[s]. */
 int acktr_gail_scale_rows_f32(float* reward, const float* scale, int S, int N, void* stream);
 
+/* ---- recurrent bases: the element-wise links of nn.GRU as driven by NNBase._forward_gru (model.py:89-95,111-166).
+ * Gate order r, z, n; rows are environments, [N, H] per step; the per-step products gi = x W_ih^T + b_ih and
+ * gh = (h*mask) W_hh^T + b_hh come from acktr_linear_fwd_f32.
+ * mask_rows: out[n, :] = h[n, :] * m[n]                                   (hxs * masks, model.py:113,155)
+ * gates_fwd: r = s(gi_r + gh_r), z = s(gi_z + gh_z), n = tanh(gi_n + r*gh_n), h_out = n + z*(hm - n);
+ *            gi_rzn [N,3H] holds gi on entry and (r, z, n) on return; hm_next = h_out * m_next[n] when both given.
+ * gates_bwd: dh = dout + (last ? 0 : carry * m_next[n]); rzn_dgi (r,z,n on entry) <- d gi; gh_dgh (gh on entry) <-
+ *            d gh; carry <- dh * z, onto which the caller accumulates d gh W_hh (acktr_linear_dgrad_f32, accumulate). */
+int acktr_gru_mask_rows_f32(const float* h, const float* m, float* out, int N, int H, void* stream);
+int acktr_gru_gates_fwd_f32(float* gi_rzn, const float* gh, const float* hm, const float* m_next, float* h_out,
+                            float* hm_next, int N, int H, void* stream);
+int acktr_gru_gates_bwd_f32(const float* dout, const float* m_next, float* rzn_dgi, float* gh_dgh, const float* hm,
+                            float* carry, int last, int N, int H, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,9 @@ _PROTOS = {
     'acktr_gail_reward_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'acktr_gail_returns_moments_f32': (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'acktr_gail_scale_rows_f32': (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    'acktr_gru_mask_rows_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
+    'acktr_gru_gates_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
+    'acktr_gru_gates_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
 }
 
 

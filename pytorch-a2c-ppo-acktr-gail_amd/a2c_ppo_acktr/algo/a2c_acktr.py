@@ -74,11 +74,23 @@ class A2C_ACKTR():
             returns = rollouts.returns[:T].view(rows)
             ac.bind_grads()
             inv_batch = 1.0 / rows
-            idx = None
-            if self.dp.active:                     # shard the full batch over ranks (rows are independent)
+            idx = hxs = masks = None
+            if ac.is_recurrent:                    # a2c_acktr.py:38-43: all N trajectories, states stored at step 0
+                if self.acktr:
+                    raise NotImplementedError('Recurrent policy is not implemented for ACKTR')   # arguments.py:157-159
+                H = ac.recurrent_hidden_state_size
+                hxs = rollouts.recurrent_hidden_states[0].view(-1, H)
+                masks = rollouts.masks[:T].reshape(rows, 1)
+                if self.dp.active:                 # shard by env: a trajectory cannot be split
+                    lo, hi = self.dp.bounds(N)
+                    mine = torch.arange(lo, hi, device=dev)
+                    idx = rollouts.recurrent_rows(mine)
+                    hxs = hxs[lo:hi]
+                    masks = rollouts._gather(masks, idx, rows)
+            elif self.dp.active:                   # shard the full batch over ranks (rows are independent)
                 lo, hi = self.dp.bounds(rows)
                 idx = torch.arange(lo, hi, device=dev)
-            acts = engine.forward(ac, obs_flat, gather_idx=idx)                         # a2c_acktr.py:38-43
+            acts = engine.forward(ac, obs_flat, gather_idx=idx, rnn_hxs=hxs, masks=masks)   # a2c_acktr.py:38-43
             if self.acktr and self.optimizer.steps % self.optimizer.Ts == 0:
                 self.optimizer.accumulate_stats(acts, actions, idx, inv_batch, self.dp)  # a2c_acktr.py:53-68
             engine.policy_loss(ac, acts, engine.ALGO_A2C, actions, loss_acc, inv_batch, returns=returns,

@@ -63,6 +63,8 @@ class KFACOptimizer(optim.Optimizer):
                 else:
                     split_bias(child)
 
+        if getattr(model, 'is_recurrent', False):
+            raise NotImplementedError('Recurrent policy is not implemented for ACKTR')       # arguments.py:157-159
         split_bias(model)
         model.rebind_flat()
 

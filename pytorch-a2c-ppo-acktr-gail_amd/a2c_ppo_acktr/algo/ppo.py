@@ -102,7 +102,7 @@ class PPO():
     # one minibatch step = ppo.py:57-84
     def _fwd_bwd(self, b):
         ac = self.actor_critic
-        acts = engine.forward(ac, b['obs'], gather_idx=b['idx'])
+        acts = engine.forward(ac, b['obs'], gather_idx=b['idx'], rnn_hxs=b.get('hxs'), masks=b.get('masks'))
         engine.policy_loss(ac, acts, engine.ALGO_PPO, b['actions'], b['loss_acc'], b['inv_batch'],
                            old_logp=b['old_logp'], old_values=b['old_values'], returns=b['returns'], adv=b['adv'],
                            gather_idx=b['idx'], clip=self.clip_param, value_coef=self.value_loss_coef,
@@ -112,7 +112,7 @@ class PPO():
     def update(self, rollouts):
         ac = self.actor_critic
         if ac.is_recurrent:
-            raise NotImplementedError('recurrent policies are outside the MI355X build')
+            return self._update_recurrent(rollouts)
         T, N = rollouts.rewards.size()[0:2]
         rows = T * N
         dev = rollouts.rewards.device
@@ -168,4 +168,39 @@ class PPO():
             self.dp.all_reduce_sum_(self._loss_acc)
             num_updates = self.ppo_epoch * self.num_mini_batch
             vl, al, en = (self._loss_acc / num_updates).tolist()                    # the only host sync
+        return vl, al, en
+
+    def _update_recurrent(self, rollouts):
+        """ppo.py:34-96 with `recurrent_generator` (ppo.py:44-46): a minibatch is the whole trajectory of
+        N // num_mini_batch envs.  Rows are addressed through one index tensor (t*N + env), so the fused gathers of
+        the feed-forward path serve here too; data-parallel ranks split the ENVS of a minibatch."""
+        ac = self.actor_critic
+        T, N = rollouts.rewards.size()[0:2]
+        rows = T * N
+        dev = rollouts.rewards.device
+        H = ac.recurrent_hidden_state_size
+        with torch.no_grad():
+            adv = rollouts.normalized_advantages()                                   # ppo.py:35-37
+            loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
+            masks_flat = rollouts.masks[:T].reshape(rows, 1)
+            b = dict(obs=rollouts.obs[:T].view(rows, *rollouts.obs.size()[2:]), actions=rollouts.actions.view(rows, -1),
+                     old_values=rollouts.value_preds[:T].view(rows), returns=rollouts.returns[:T].view(rows),
+                     old_logp=rollouts.action_log_probs.view(rows), adv=adv.view(rows), loss_acc=loss_acc)
+            ac.bind_grads()
+            self.optimizer.prepare()
+            n_steps = 0
+            for e in range(self.ppo_epoch):
+                for envs in rollouts.recurrent_env_batches(self.num_mini_batch):
+                    lo, hi = self.dp.bounds(envs.numel())
+                    mine = envs[lo:hi].to(dev)
+                    b['idx'] = rollouts.recurrent_rows(mine)
+                    b['hxs'] = rollouts._gather(rollouts.recurrent_hidden_states[0].view(N, H), mine, N)
+                    b['masks'] = rollouts._gather(masks_flat, b['idx'], rows)
+                    b['inv_batch'] = 1.0 / (T * envs.numel())
+                    self._fwd_bwd(b)
+                    self.dp.all_reduce_sum_(ac.flat_grads)
+                    self.optimizer.step(self.max_grad_norm)                            # ppo.py:82-84
+                    n_steps += 1
+            self.dp.all_reduce_sum_(loss_acc)
+            vl, al, en = (loss_acc / n_steps).tolist()
         return vl, al, en

@@ -7,6 +7,10 @@ CNN  (reference model.py:189-195, distributions.py:71-73):
 MLP  (reference model.py:220-229, distributions.py:86-95):
     separate tanh towers for critic and actor, value head on the critic tower, mean head on the actor.
 
+Recurrent bases (model.py:111-166): a GRU between the trunk and the heads (CNN: on the FC features; MLP: on the raw
+inputs, the towers then read the GRU output).  `gru_forward` / `gru_backward` below run it over [T*N] rows (row
+t*N+n) as one input GEMM for all steps + per step one hidden GEMM and one gate kernel (csrc/gru.hip).
+
 `gather_idx` (int64 device tensor) makes every rollout-side read go through the minibatch index, so
 storage.py:127's gathered copies are never made on the NatureCNN path (fused into conv1's loader).
 """
@@ -92,9 +96,89 @@ def head_views(policy, flat):
     return (flat[ow:ow + (1 + A) * hidden].view(1 + A, hidden), flat[ob:ob + 1 + A])
 
 
-def forward(policy, inputs, gather_idx=None):
+def gru_params(policy):
+    g = policy.base.gru
+    return g.weight_ih_l0, g.weight_hh_l0, g.bias_ih_l0, g.bias_hh_l0
+
+
+def gru_forward(policy, a, x_seq, hxs, masks):
+    """model.py:111-166.  x_seq [T*N, I] (row t*N+n), hxs [N, H], masks [T*N(,1)].  The carried state is multiplied by
+    masks[t] at every step -- the same arithmetic as the reference's chunking, whose skipped multiplications are by
+    exactly 1.0.  Leaves on `a`: gru_out [T*N, H], hxs_out [N, H] (view of the last step) and what BPTT needs
+    (gru_rzn = r,z,n per row; gru_gh = W_hh products; gru_hm = masked previous states; gru_x, gru_masks)."""
+    if hxs is None or masks is None:
+        raise RuntimeError('a recurrent policy needs rnn_hxs and masks')
+    dev = x_seq.device
+    w_ih, w_hh, b_ih, b_hh = gru_params(policy)
+    H = w_hh.shape[1]
+    hxs = hxs.to(dev, f32).reshape(-1, H).contiguous()
+    N = hxs.shape[0]
+    B = x_seq.shape[0]
+    T = B // N
+    if T * N != B or T < 1:
+        raise RuntimeError('recurrent forward: %d input rows are not a multiple of the %d hidden-state rows' % (B, N))
+    masks = masks.to(dev, f32).reshape(-1).contiguous()
+    if masks.numel() != B:
+        raise RuntimeError('recurrent forward: expected %d mask entries, got %d' % (B, masks.numel()))
+    L = _hip.lib()
+    stream = _hip.cur_stream(dev)
+    gi = ops.linear_fwd(x_seq, w_ih, b_ih, None)                       # all steps at once: [T*N, 3H]
+    gh = torch.empty(B, 3 * H, dtype=f32, device=dev)
+    hm = torch.empty(B, H, dtype=f32, device=dev)
+    out = torch.empty(B, H, dtype=f32, device=dev)
+    _hip.check(L.acktr_gru_mask_rows_f32(_hip.dev_ptr(hxs), _hip.dev_ptr(masks), _hip.dev_ptr(hm), N, H, stream),
+               'acktr_gru_mask_rows_f32')
+    for t in range(T):
+        s = slice(t * N, (t + 1) * N)
+        ops.linear_fwd(hm[s], w_hh, b_hh, None, out=gh[s])
+        nxt = t + 1 < T
+        rc = L.acktr_gru_gates_fwd_f32(_hip.dev_ptr(gi[s]), _hip.dev_ptr(gh[s]), _hip.dev_ptr(hm[s]),
+                                       _hip.dev_ptr(masks[(t + 1) * N:(t + 2) * N]) if nxt else None,
+                                       _hip.dev_ptr(out[s]),
+                                       _hip.dev_ptr(hm[(t + 1) * N:(t + 2) * N]) if nxt else None, N, H, stream)
+        _hip.check(rc, 'acktr_gru_gates_fwd_f32')
+    a.gru_x, a.gru_masks, a.gru_rzn, a.gru_gh, a.gru_hm = x_seq, masks, gi, gh, hm
+    a.gru_T, a.gru_N = T, N
+    a.gru_out, a.hxs_out = out, out[(T - 1) * N:]
+    return out
+
+
+def gru_backward(policy, a, dout, gflat, wgrad=True, dx_gate_src=None, dx_gate=None, need_dx=True):
+    """BPTT through gru_forward.  dout [T*N, H] = d loss / d gru_out.  Overwrites the saved gates with d gi / d gh,
+    writes the four GRU parameter gradients into `gflat` and returns d loss / d x_seq (gated by `dx_gate` on
+    `dx_gate_src` when the GRU input was an activation output), or None."""
+    w_ih, w_hh, b_ih, b_hh = gru_params(policy)
+    T, N = a.gru_T, a.gru_N
+    H = w_hh.shape[1]
+    dev = dout.device
+    L = _hip.lib()
+    stream = _hip.cur_stream(dev)
+    dout = dout.contiguous()
+    carry = torch.empty(N, H, dtype=f32, device=dev)
+    rzn, gh, hm, masks = a.gru_rzn, a.gru_gh, a.gru_hm, a.gru_masks
+    for t in range(T - 1, -1, -1):
+        s = slice(t * N, (t + 1) * N)
+        last = t == T - 1
+        rc = L.acktr_gru_gates_bwd_f32(_hip.dev_ptr(dout[s]),
+                                       None if last else _hip.dev_ptr(masks[(t + 1) * N:(t + 2) * N]),
+                                       _hip.dev_ptr(rzn[s]), _hip.dev_ptr(gh[s]), _hip.dev_ptr(hm[s]),
+                                       _hip.dev_ptr(carry), 1 if last else 0, N, H, stream)
+        _hip.check(rc, 'acktr_gru_gates_bwd_f32')
+        if t > 0:                                                      # d hm[t] += d gh[t] W_hh  (d hxs itself is unused)
+            ops.linear_dgrad(gh[s], w_hh, out=carry, accumulate=True)
+    if wgrad:
+        gv = lambda p: policy.grad_view(p, gflat)
+        ops.linear_wgrad(rzn, a.gru_x, gv(w_ih), gv(b_ih))
+        ops.linear_wgrad(gh, hm, gv(w_hh), gv(b_hh))
+    if need_dx:
+        return ops.linear_dgrad(rzn, w_ih, gate_src=dx_gate_src, gate=dx_gate)
+    return None
+
+
+def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None):
     inputs = inputs.contiguous()
     _check_input(policy, inputs, gather_idx)
+    rec = policy.is_recurrent
     if is_cnn(policy):
         L = cnn_layer_params(policy)
         a = Acts(True)
@@ -105,8 +189,9 @@ def forward(policy, inputs, gather_idx=None):
         a.y3 = ops.conv2d_fwd(a.y2, L['conv3'][0], L['conv3'][1].view(-1), 1)
         a.flat3 = a.y3.view(a.y3.shape[0], -1)
         a.feat = ops.linear_fwd(a.flat3, L['fc'][0], L['fc'][1].view(-1), 'relu')
+        a.head_in = gru_forward(policy, a, a.feat, rnn_hxs, masks) if rec else a.feat
         wh, bh = head_views(policy, policy.flat_params)
-        a.head = ops.linear_fwd(a.feat, wh, bh, None)
+        a.head = ops.linear_fwd(a.head_in, wh, bh, None)
         return a
     L = mlp_layer_params(policy)
     a = Acts(False)
@@ -114,6 +199,9 @@ def forward(policy, inputs, gather_idx=None):
         from .storage import RolloutStorage
         inputs = RolloutStorage._gather(inputs, gather_idx, inputs.shape[0])
     a.obs = inputs
+    if rec:
+        inputs = gru_forward(policy, a, inputs, rnn_hxs, masks)
+    a.tower_in = inputs
     a.hc1 = ops.linear_fwd(inputs, L['c0'][0], L['c0'][1].view(-1), 'tanh')
     a.hc2 = ops.linear_fwd(a.hc1, L['c2'][0], L['c2'][1].view(-1), 'tanh')
     a.ha1 = ops.linear_fwd(inputs, L['a0'][0], L['a0'][1].view(-1), 'tanh')
@@ -153,8 +241,12 @@ def backward(policy, acts, gflat, keep=False, wgrad=True):
         w3, w2, w1 = L['conv3'][0], L['conv2'][0], L['conv1'][0]
         if wgrad:
             gwh, gbh = head_views(policy, gflat)
-            ops.linear_wgrad(acts.dhead, acts.feat, gwh, gbh)
-        dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
+            ops.linear_wgrad(acts.dhead, acts.head_in, gwh, gbh)
+        if policy.is_recurrent:
+            dgru = ops.linear_dgrad(acts.dhead, wh)
+            dfeat = gru_backward(policy, acts, dgru, gflat, wgrad=wgrad, dx_gate_src=acts.feat, dx_gate='relu')
+        else:
+            dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
         if wgrad:
             ops.linear_wgrad(dfeat, acts.flat3, gv(L['fc'][0]), gv(L['fc'][1]).view(-1))
         dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
@@ -180,10 +272,14 @@ def backward(policy, acts, gflat, keep=False, wgrad=True):
     if wgrad:
         ops.linear_wgrad(acts.dv, acts.hc2, gv(L['critic'][0]), gv(L['critic'][1]).view(-1))
         ops.linear_wgrad(dhc2, acts.hc1, gv(L['c2'][0]), gv(L['c2'][1]).view(-1))
-        ops.linear_wgrad(dhc1, acts.obs, gv(L['c0'][0]), gv(L['c0'][1]).view(-1))
+        ops.linear_wgrad(dhc1, acts.tower_in, gv(L['c0'][0]), gv(L['c0'][1]).view(-1))
         ops.linear_wgrad(acts.dmean, acts.ha2, gv(L['mean'][0]), gv(L['mean'][1]).view(-1))
         ops.linear_wgrad(dha2, acts.ha1, gv(L['a2'][0]), gv(L['a2'][1]).view(-1))
-        ops.linear_wgrad(dha1, acts.obs, gv(L['a0'][0]), gv(L['a0'][1]).view(-1))
+        ops.linear_wgrad(dha1, acts.tower_in, gv(L['a0'][0]), gv(L['a0'][1]).view(-1))
+    if policy.is_recurrent:                     # both towers read the GRU output: d gru_out = dhc1 Wc0 + dha1 Wa0
+        dgru = ops.linear_dgrad(dhc1, L['c0'][0])
+        ops.linear_dgrad(dha1, L['a0'][0], out=dgru, accumulate=True)
+        gru_backward(policy, acts, dgru, gflat, wgrad=wgrad, need_dx=False)
     if keep:
         acts.dhc2, acts.dhc1, acts.dha2, acts.dha1 = dhc2, dhc1, dha2, dha1
 
@@ -236,8 +332,8 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
 # ----------------------------------------------------------------------------------------------
 class EvalActions(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, policy, inputs, action, *params):
-        acts = forward(policy, inputs)
+    def forward(ctx, policy, inputs, action, rnn_hxs, masks, *params):
+        acts = forward(policy, inputs, rnn_hxs=rnn_hxs, masks=masks)
         B = inputs.shape[0]
         A = policy.dist.num_outputs
         dev = inputs.device
@@ -257,10 +353,12 @@ class EvalActions(torch.autograd.Function):
         _hip.check(rc, 'acktr_dist_fwd_f32')
         ctx.policy, ctx.acts, ctx.act = policy, acts, act
         ctx.nparams = len(params)
-        return acts.value().clone(), logp, ent.mean()
+        hxs_out = acts.hxs_out.clone() if policy.is_recurrent else torch.zeros(1, device=dev)
+        ctx.mark_non_differentiable(hxs_out)
+        return acts.value().clone(), logp, ent.mean(), hxs_out
 
     @staticmethod
-    def backward(ctx, dvalue, dlogp, dent):
+    def backward(ctx, dvalue, dlogp, dent, _dhxs):
         policy, acts, act = ctx.policy, ctx.acts, ctx.act
         B = act.shape[0]
         A = policy.dist.num_outputs
@@ -287,4 +385,4 @@ class EvalActions(torch.autograd.Function):
         backward(policy, acts, gflat)
         grads = tuple(policy.grad_view(p, gflat) for p in policy.parameters())
         assert len(grads) == ctx.nparams
-        return (None, None, None) + grads
+        return (None, None, None, None, None) + grads

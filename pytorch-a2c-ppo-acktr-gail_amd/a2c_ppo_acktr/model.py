@@ -10,8 +10,10 @@ csrc/ through `engine.py`.  All parameters of a Policy are views into ONE flat f
 (`policy.flat_params`, gradient twin `policy.flat_grads`), which is what lets clip-norm + optimiser
 be two launches and the data-parallel all-reduce a single bucket.
 
-Not built (reference features outside the north-star path): recurrent (GRU) bases and the broken
-Bernoulli head (reference distributions.py:49-50, F11).
+Recurrent bases (`base_kwargs={'recurrent': True}`, model.py:89-95,111-166): `base.gru` is an nn.GRU used as a
+parameter container like the rest; the sequence runs in engine.gru_forward / gru_backward.
+
+Not built: the broken Bernoulli head (reference distributions.py:49-50, F11).
 """
 import numpy as np
 import torch
@@ -72,7 +74,7 @@ class Policy(nn.Module):
         """Groups of parameters that must be contiguous; each group starts 16-byte aligned."""
         if isinstance(self.base, CNNBase):
             w = engine.cnn_layer_params(self)
-            groups = []
+            groups = [[p] for p in self.base.gru.parameters()] if self.base.is_recurrent else []
             for name in ('conv1', 'conv2', 'conv3', 'fc'):
                 groups.append([w[name][0]])
                 groups.append([w[name][1]])
@@ -154,22 +156,28 @@ class Policy(nn.Module):
     def act(self, inputs, rnn_hxs, masks, deterministic=False):
         """reference model.py:54-66 (rollout side; forward kernels without grad, sampling via torch RNG)."""
         with torch.no_grad():
-            acts = engine.forward(self, inputs)
+            acts = engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks)
             dist = self._dist_from_head(acts)
             action = dist.mode() if deterministic else dist.sample()
             action_log_probs = dist.log_probs(action)
+            if self.is_recurrent:
+                rnn_hxs = acts.hxs_out.clone()
             return acts.value().clone(), action, action_log_probs, rnn_hxs
 
     def get_value(self, inputs, rnn_hxs, masks):
         """reference model.py:68-70."""
         with torch.no_grad():
-            return engine.forward(self, inputs).value().clone()
+            return engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks).value().clone()
 
     def evaluate_actions(self, inputs, rnn_hxs, masks, action):
         """reference model.py:72-79: (value [B,1], action_log_probs [B,1], dist_entropy scalar, rnn_hxs).
         Differentiable w.r.t. every parameter through a torch.autograd.Function whose forward and
         backward are the HIP kernels."""
-        value, logp, ent = engine.EvalActions.apply(self, inputs, action, *list(self.parameters()))
+        if self.is_recurrent:
+            value, logp, ent, hxs = engine.EvalActions.apply(self, inputs, action, rnn_hxs, masks,
+                                                             *list(self.parameters()))
+            return value, logp, ent, hxs
+        value, logp, ent, _ = engine.EvalActions.apply(self, inputs, action, None, None, *list(self.parameters()))
         return value, logp, ent, rnn_hxs
 
 
@@ -178,8 +186,13 @@ class NNBase(nn.Module):
         super(NNBase, self).__init__()
         self._hidden_size = hidden_size
         self._recurrent = recurrent
-        if recurrent:
-            raise NotImplementedError('recurrent (GRU) policies are outside the MI355X build (SURVEY 8(f) rank 4)')
+        if recurrent:                                   # reference model.py:89-95 (same initialiser calls, same order)
+            self.gru = nn.GRU(recurrent_input_size, hidden_size)
+            for name, param in self.gru.named_parameters():
+                if 'bias' in name:
+                    nn.init.constant_(param, 0)
+                elif 'weight' in name:
+                    nn.init.orthogonal_(param)
 
     @property
     def is_recurrent(self):
@@ -220,6 +233,9 @@ class CNNBase(NNBase):
 class MLPBase(NNBase):
     def __init__(self, num_inputs, recurrent=False, hidden_size=64):
         super(MLPBase, self).__init__(recurrent, num_inputs, hidden_size)
+
+        if recurrent:
+            num_inputs = hidden_size
 
         init_ = lambda m: init(m, nn.init.orthogonal_, lambda x: nn.init.
                                constant_(x, 0), np.sqrt(2))

@@ -168,6 +168,46 @@ class RolloutStorage(object):
             yield obs_batch, recurrent_hidden_states_batch, actions_batch, \
                 value_preds_batch, return_batch, masks_batch, old_action_log_probs_batch, adv_targ
 
+    def recurrent_env_batches(self, num_mini_batch):
+        """The env groups recurrent_generator walks (reference storage.py:146-153): ONE torch.randperm over the
+        processes on the CPU default generator per call, consecutive groups of N // num_mini_batch envs.
+        Returns a list of int64 CPU tensors."""
+        num_processes = self.rewards.size(1)
+        assert num_processes >= num_mini_batch, (
+            "PPO requires the number of processes ({}) "
+            "to be greater than or equal to the number of "
+            "PPO mini batches ({}).".format(num_processes, num_mini_batch))
+        num_envs_per_batch = num_processes // num_mini_batch
+        perm = torch.randperm(num_processes)
+        if num_processes % num_envs_per_batch != 0:
+            # the reference's loop then reads perm[] out of range in its last batch (storage.py:153,164)
+            raise IndexError('recurrent_generator: %d processes do not split into batches of %d'
+                             % (num_processes, num_envs_per_batch))
+        return [perm[s:s + num_envs_per_batch] for s in range(0, num_processes, num_envs_per_batch)]
+
+    def recurrent_rows(self, envs):
+        """Flat storage rows t*N + env of whole trajectories, ordered row t*Nb + j (storage.py:176-199), as an int64
+        device tensor."""
+        T, N = self.rewards.size()[0:2]
+        dev = self.rewards.device
+        envs = envs.to(dev)
+        return (torch.arange(T, device=dev).view(T, 1) * N + envs.view(1, -1)).reshape(-1)
+
     def recurrent_generator(self, advantages, num_mini_batch):
-        # reference storage.py:145-202 -- recurrent policies are outside this build's scope
-        raise NotImplementedError('recurrent_generator: the recurrent path is not part of the MI355X build yet')
+        """reference storage.py:145-202: whole trajectories of N // num_mini_batch envs per batch, flattened to
+        [T*Nb, ...] (row t*Nb + j); hidden states are the ones stored at step 0.  Gathered on the GPU."""
+        T, N = self.rewards.size()[0:2]
+        rows = T * N
+        for envs in self.recurrent_env_batches(num_mini_batch):
+            indices = self.recurrent_rows(envs)
+            g = lambda t: self._gather(t[:T].view(rows, *t.size()[2:]), indices, rows)
+            obs_batch = g(self.obs)
+            recurrent_hidden_states_batch = self._gather(self.recurrent_hidden_states[0], envs.to(indices.device), N)
+            actions_batch = g(self.actions)
+            value_preds_batch = g(self.value_preds)
+            return_batch = g(self.returns)
+            masks_batch = g(self.masks)
+            old_action_log_probs_batch = g(self.action_log_probs)
+            adv_targ = self._gather(advantages.contiguous().view(rows, 1), indices, rows)
+            yield obs_batch, recurrent_hidden_states_batch, actions_batch, \
+                value_preds_batch, return_batch, masks_batch, old_action_log_probs_batch, adv_targ

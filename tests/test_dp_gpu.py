@@ -43,15 +43,23 @@ def _worker(rank, world, port, out_dir, algo_name):
     from a2c_ppo_acktr.model import Policy
     T, N, A = 6, 12, 6                                   # 72 samples: minibatches of 36 -> shards of 18
     torch.manual_seed(3)
-    pol = Policy((4, 84, 84), Discrete(A))
+    rec = algo_name.endswith('_rec')                     # recurrent: ranks split the ENVS of a minibatch
+    pol = Policy((4, 84, 84), Discrete(A), base_kwargs={'recurrent': rec})
     pol.to('cuda')
-    ro = synth.make_rollouts(T, N, (4, 84, 84), 'discrete', A, salt=610)
+    ro = synth.make_rollouts(T, N, (4, 84, 84), 'discrete', A, salt=610, p_mask=0.8 if rec else 0.97,
+                             hidden=512 if rec else None)
     rs = make_storage(ro, (4, 84, 84), Discrete(A))
-    if algo_name == 'ppo':
+    if rec:
+        rs.recurrent_hidden_states = t(ro['recurrent_hidden_states']).cuda()
+    if algo_name in ('ppo', 'ppo_rec'):
         rs.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
         agent = algo.PPO(pol, clip_param=0.1, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01,
                          lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
         n_upd = 3                                        # the third update replays the captured graphs
+    elif algo_name == 'a2c_rec':
+        rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
+        agent = algo.A2C_ACKTR(pol, 0.5, 0.01, lr=7e-4, eps=1e-5, alpha=0.99, max_grad_norm=0.5)
+        n_upd = 2
     else:
         rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
         agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
@@ -71,7 +79,7 @@ def _worker(rank, world, port, out_dir, algo_name):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('algo_name', ['ppo', 'acktr'])
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'ppo_rec', 'a2c_rec'])
 def test_two_rank_update_matches_single_process(tmp_path, algo_name):
     out = str(tmp_path)
     mp.spawn(_worker, args=(1, 0, out, algo_name), nprocs=1, join=True)
@@ -80,4 +88,4 @@ def test_two_rank_update_matches_single_process(tmp_path, algo_name):
     two = torch.load(os.path.join(out, '%s_w2.pt' % algo_name))
     np.testing.assert_allclose(two['losses'].numpy(), one['losses'].numpy(), rtol=2e-4, atol=1e-6)
     err = float((two['flat'] - one['flat']).norm() / one['flat'].norm())
-    assert err < (2e-5 if algo_name == 'ppo' else 1e-3), err
+    assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err

@@ -62,11 +62,12 @@ int acktr_gather_rows(const void* src, const int64_t* idx, void* dst, long rows,
  * gather_idx (nullable, int64[B]): image b is read from x + gather_idx[b]*C*H*W -- the minibatch
  * gather of storage.py:127 fused into the loader.  x, w 16-byte aligned.  `workspace` (nullable, 16-byte
  * aligned, ..._workspace_bytes) holds the weights re-ordered for the LDS-stationary kernel; without it the
- * generic tile-GEMM kernel runs. */
+ * generic tile-GEMM kernel runs.  prepacked = 1: the workspace already holds this layer's re-ordered weights (written
+ * by acktr_conv2d_pack_weights_f32 since `w` last changed) and the re-ordering launch is skipped. */
 long acktr_conv2d_fwd_workspace_bytes(int C, int H, int W, int OC, int KH, int KW, int S);
 int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
                          int B, int C, int H, int W, int OC, int KH, int KW, int S, float in_scale, int relu,
-                         void* workspace, long workspace_bytes, void* stream);
+                         void* workspace, long workspace_bytes, int prepacked, void* stream);
 
 /* autograd backward of the same Conv2d w.r.t. weight and bias: dw[OC,C,KH,KW] = in_scale * sum dy (x) patches,
  * db[OC] = sum dy (db nullable).  Split-K slabs live in `workspace` (see ..._workspace_bytes); the
@@ -78,10 +79,21 @@ int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const floa
 
 /* autograd backward w.r.t. the input: dx[B,C,H,W] = conv_transpose(dy, w) (* (x_act > 0) when x_act is
  * given: the ReLU backward of the layer that produced x, model.py:177-179).  `workspace` (16-byte aligned,
- * ..._workspace_bytes) receives the re-ordered weights and the zero-padded copy of dy. */
+ * ..._workspace_bytes) receives the re-ordered weights and the zero-padded copy of dy; prepacked as for the forward. */
 long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, int OC, int KH, int KW, int S);
 int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
-                           int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, void* stream);
+                           int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, int prepacked,
+                           void* stream);
+
+/* Re-ordered weights of up to 8 conv layers in ONE launch (no counterpart call in the reference: it is the weight
+ * preparation the forward / dgrad entry points above otherwise launch themselves, model.py:176-179).  Each job names a
+ * layer (C, H, W, OC, KH, KW, S as for the matching entry point; dgrad = 0 forward, 1 input-gradient) and that entry
+ * point's workspace; the layer must be one the LDS-stationary kernel handles (NatureCNN's shapes), else -1. */
+typedef struct acktr_conv_pack_job {
+    const float* w; void* workspace; long workspace_bytes;
+    int C, H, W, OC, KH, KW, S, dgrad;
+} acktr_conv_pack_job;
+int acktr_conv2d_pack_weights_f32(const acktr_conv_pack_job* jobs, int count, void* stream);
 
 /* nn.Linear forward -- model.py:180,185,208-216, distributions.py:69,83.
  * y[B,OUT] = act(x[B,IN] w[OUT,IN]^T + bias);  act: 0 none, 1 relu, 2 tanh.  workspace (nullable) enables split-K

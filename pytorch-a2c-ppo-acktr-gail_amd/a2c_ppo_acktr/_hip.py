@@ -34,6 +34,12 @@ class LossArgs(ctypes.Structure):
                 ('dlogstd', c_p), ('dlogstd_rows', c_p), ('logp_out', c_p), ('loss_acc', c_p),
                 ('workspace', c_p), ('workspace_bytes', c_l)]
 
+class ConvPackJob(ctypes.Structure):
+    """struct acktr_conv_pack_job (include/acktr_hip.h)"""
+    _fields_ = [('w', c_p), ('workspace', c_p), ('workspace_bytes', c_l),
+                ('C', c_i), ('H', c_i), ('W', c_i), ('OC', c_i), ('KH', c_i), ('KW', c_i), ('S', c_i), ('dgrad', c_i)]
+
+
 class EigJob(ctypes.Structure):
     """struct acktr_eig_job (include/acktr_hip.h)"""
     _fields_ = [('a_inout_qt', c_p), ('d', c_p), ('n', c_i), ('reserved', c_i)]
@@ -49,11 +55,12 @@ _PROTOS = {
     'acktr_adv_normalize_f32': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p]),
     'acktr_gather_rows': (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
     'acktr_conv2d_fwd_workspace_bytes': (c_l, [c_i] * 7),
-    'acktr_conv2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_i, c_p, c_l, c_p]),
+    'acktr_conv2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_i, c_p, c_l, c_i, c_p]),
     'acktr_conv2d_wgrad_workspace_bytes': (c_l, [c_i] * 8),
     'acktr_conv2d_wgrad_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_p, c_l, c_p]),
     'acktr_conv2d_dgrad_workspace_bytes': (c_l, [c_i] * 8),
-    'acktr_conv2d_dgrad_f32': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_l, c_p]),
+    'acktr_conv2d_dgrad_f32': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_l, c_i, c_p]),
+    'acktr_conv2d_pack_weights_f32': (c_i, [c_p, c_i, c_p]),
     'acktr_linear_fwd_workspace_bytes': (c_l, [c_i, c_i, c_i]),
     'acktr_linear_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_l, c_p]),
     'acktr_linear_dgrad_f32': (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),

@@ -183,10 +183,18 @@ def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None):
         L = cnn_layer_params(policy)
         a = Acts(True)
         a.obs, a.idx = inputs, gather_idx
+        B = inputs.shape[0] if gather_idx is None else gather_idx.numel()
+        # all five re-ordered weight images of the step (three forward, two dgrad) in one launch; the parameters do
+        # not change between this forward and its backward
+        pk = ops.pack_conv_weights([('f1', L['conv1'][0], 4, 84, False), ('f2', L['conv2'][0], 2, 20, False),
+                                    ('f3', L['conv3'][0], 1, 9, False), ('d3', L['conv3'][0], 1, 9, True),
+                                    ('d2', L['conv2'][0], 2, 20, True)], B,
+                                   policy.__dict__.setdefault('_pack_ws', {}))
+        a.packs = pk
         a.y1 = ops.conv2d_fwd(inputs, L['conv1'][0], L['conv1'][1].view(-1), 4, in_scale=1.0 / 255.0, relu=True,
-                              gather_idx=gather_idx)
-        a.y2 = ops.conv2d_fwd(a.y1, L['conv2'][0], L['conv2'][1].view(-1), 2)
-        a.y3 = ops.conv2d_fwd(a.y2, L['conv3'][0], L['conv3'][1].view(-1), 1)
+                              gather_idx=gather_idx, packed=pk.get('f1'))
+        a.y2 = ops.conv2d_fwd(a.y1, L['conv2'][0], L['conv2'][1].view(-1), 2, packed=pk.get('f2'))
+        a.y3 = ops.conv2d_fwd(a.y2, L['conv3'][0], L['conv3'][1].view(-1), 1, packed=pk.get('f3'))
         a.flat3 = a.y3.view(a.y3.shape[0], -1)
         a.feat = ops.linear_fwd(a.flat3, L['fc'][0], L['fc'][1].view(-1), 'relu')
         a.head_in = gru_forward(policy, a, a.feat, rnn_hxs, masks) if rec else a.feat
@@ -233,7 +241,11 @@ def backward(policy, acts, gflat, keep=False, wgrad=True):
     accumulates).  With keep=True the pre-activation gradients of every layer stay on `acts`
     (dy1, dy2, dy3, dfeat / dhc*, dha*) -- the `grad_output`s KFAC's backward hooks would see.
     wgrad=False runs the data-gradient chain only (the sampled-Fisher pass of ACKTR needs no
-    parameter gradients, a2c_acktr.py:66-70)."""
+    parameter gradients, a2c_acktr.py:66-70).
+    (Measured and dropped: issuing the weight-gradient launches on a second stream -- a parallel branch of the
+    captured graph -- to fill the dispatch bubbles of the data-gradient chain.  11.63 ms per update became 12.51
+    with every wgrad on the side stream and 11.70-11.75 with only the head / FC ones: the big kernels each fill
+    the chip and evict each other's L2 working sets.)"""
     gv = lambda p: policy.grad_view(p, gflat)
     if acts.cnn:
         L = cnn_layer_params(policy)
@@ -252,10 +264,10 @@ def backward(policy, acts, gflat, keep=False, wgrad=True):
         dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
         if wgrad:
             ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
-        dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1)
+        dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1, packed=acts.packs.get('d3'))
         if wgrad:
             ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1))
-        dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2)
+        dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2, packed=acts.packs.get('d2'))
         if wgrad:
             ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1),
                              in_scale=1.0 / 255.0, gather_idx=acts.idx)

@@ -68,7 +68,37 @@ def _conv_out(H, K, S):
     return (H - K) // S + 1
 
 
-def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out=None):
+def pack_conv_weights(layers, B, cache):
+    """Re-ordered weights of several conv layers in ONE launch.  layers: list of (key, w, stride, in_hw, dgrad); the
+    result maps key -> workspace tensor to hand to conv2d_fwd / conv2d_dgrad as `packed`.  Layers the stationary
+    kernels do not cover are left out (those entry points then prepare their weights themselves).  `cache` (a dict
+    owned by the policy) keeps the workspaces: they must survive from a forward to its backward, so they cannot be
+    the process-wide scratch buffers."""
+    L = _hip.lib()
+    jobs, out = [], {}
+    for key, w, stride, hw, dgrad in layers:
+        OC, C, KH, KW = w.shape
+        if dgrad:
+            nb = L.acktr_conv2d_dgrad_workspace_bytes(B, C, hw, hw, OC, KH, KW, stride)
+        else:
+            nb = L.acktr_conv2d_fwd_workspace_bytes(C, hw, hw, OC, KH, KW, stride)
+        if not nb or (w.data_ptr() & 15):
+            continue
+        ws = cache.get(key)
+        if ws is None or ws.numel() < nb or ws.device != w.device:
+            ws = cache[key] = torch.empty(int(nb), dtype=torch.uint8, device=w.device)
+        jobs.append(_hip.ConvPackJob(w.data_ptr(), ws.data_ptr(), ws.numel(), C, hw, hw, OC, KH, KW, stride,
+                                     1 if dgrad else 0))
+        out[key] = ws
+    if jobs:
+        arr = (_hip.ConvPackJob * len(jobs))(*jobs)
+        rc = L.acktr_conv2d_pack_weights_f32(arr, len(jobs), _hip.cur_stream(layers[0][1].device))
+        if rc != 0:            # a layer outside the stationary kernels' shapes: fall back to per-call preparation
+            return {}
+    return out
+
+
+def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out=None, packed=None):
     """y = relu?(in_scale*conv2d(x[gather_idx], w) + bias); x [Bsrc,C,H,W], w [OC,C,KH,KW]."""
     OC, C, KH, KW = w.shape
     H, W = x.shape[-2], x.shape[-1]
@@ -80,12 +110,13 @@ def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out
     assert out.shape == (B, OC, OH, OW)
     L = _hip.lib()
     nb = L.acktr_conv2d_fwd_workspace_bytes(C, H, W, OC, KH, KW, stride)
-    ws = workspace(x.device, nb, tag='convfwd') if nb else None
+    ws = packed if packed is not None else (workspace(x.device, nb, tag='convfwd') if nb else None)
     with _Timed('conv%ds%d_fwd' % (KH, stride), 2.0 * B * OH * OW * OC * C * KH * KW):
         rc = L.acktr_conv2d_fwd_f32(
             _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
             B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0,
-            _p(ws, 'workspace', torch.uint8), ws.numel() if ws is not None else 0, _hip.cur_stream(x.device))
+            _p(ws, 'workspace', torch.uint8), ws.numel() if ws is not None else 0, 1 if packed is not None else 0,
+            _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_conv2d_fwd_f32')
     return out
 
@@ -111,7 +142,7 @@ def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=N
     _hip.check(rc, 'acktr_conv2d_wgrad_f32')
 
 
-def conv2d_dgrad(dy, w, x_act, stride, out=None):
+def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None):
     """dx = conv_transpose(dy, w) * (x_act > 0); x_act [B,C,H,W] is the (post-ReLU) input of the layer."""
     OC, C, KH, KW = w.shape
     B, _, OH, OW = dy.shape
@@ -120,11 +151,12 @@ def conv2d_dgrad(dy, w, x_act, stride, out=None):
         out = torch.empty(B, C, H, W, dtype=f32, device=dy.device)
     assert out.shape == (B, C, H, W) and (x_act is None or x_act.shape == out.shape)
     L = _hip.lib()
-    ws = workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride), tag='dgrad')
+    ws = packed if packed is not None else \
+        workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride), tag='dgrad')
     with _Timed('conv%ds%d_dgrad' % (KH, stride), 2.0 * dy.numel() * C * KH * KW):
         rc = L.acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
                                       B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),
-                                      _hip.cur_stream(dy.device))
+                                      1 if packed is not None else 0, _hip.cur_stream(dy.device))
     _hip.check(rc, 'acktr_conv2d_dgrad_f32')
     return out
 

@@ -198,6 +198,23 @@ static long sw_dgrad_image_floats(int geom, int OC) {
     return geom == GEOM_4S2 ? SwD2::image_floats() : SwD3::image_floats();
 }
 static long sw_dgrad_pad_floats(int geom, int B, int OC) { return (long)B * OC * 121 + 4; }
+
+// Several weight images in ONE launch (blockIdx.y = job): inside a captured graph every dependent launch costs
+// ~4.5 us, more than any of these packs takes.
+enum { PK_F1, PK_F2, PK_F3, PK_D3, PK_D2 };
+struct SwPackJob { const float* w; float* img; int kind, M, mode, CX, SD; };
+constexpr int SW_PACK_MAX_JOBS = 8;
+struct SwPackJobs { SwPackJob j[SW_PACK_MAX_JOBS]; };
+__global__ __launch_bounds__(256) void sw_pack_multi_kernel(SwPackJobs jobs) {
+    const SwPackJob jb = jobs.j[blockIdx.y];
+    switch (jb.kind) {
+        case PK_F1: sw_pack_body<SwF1>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
+        case PK_F2: sw_pack_body<SwF2>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
+        case PK_F3: sw_pack_body<SwF3>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
+        case PK_D3: sw_pack_body<SwD3>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
+        default: sw_pack_body<SwD2>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
+    }
+}
 }  // namespace acktr
 
 using namespace acktr;
@@ -218,7 +235,8 @@ extern "C" long acktr_conv2d_fwd_workspace_bytes(int C, int H, int W, int OC, in
 
 extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias,
                                     float* y, int B, int C, int H, int W, int OC, int KH, int KW, int S,
-                                    float in_scale, int relu, void* workspace, long workspace_bytes, void* stream) {
+                                    float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                                    void* stream) {
     ACKTR_ARG(x && w && y, "conv2d_fwd: null pointer");
     const bool gather_ok = true;
     CONV_COMMON_CHECKS("conv2d_fwd");
@@ -229,20 +247,20 @@ extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, c
     if (img_bytes > 0 && workspace && workspace_bytes >= img_bytes && ((uintptr_t)workspace & 15) == 0 &&
         (long)B * OC * 400 < (1L << 31)) {
         float* img = (float*)workspace;
-        int rc;
+        int rc = 0;
         if (geom == GEOM_8S4) {
-            rc = launch_sw_pack<SwF1>(w, img, OC, 0, 0, 0, s);
+            if (!prepacked) rc = launch_sw_pack<SwF1>(w, img, OC, 0, 0, 0, s);
             if (rc) return rc;
             SwFwdEpi<SwF1::SP> epi{y, bias, OC, in_scale, relu};
             return launch_conv_sw<SwF1>(x, gather_idx, img, epi, B * SwF1::SP, s);
         }
         if (geom == GEOM_4S2) {
-            rc = launch_sw_pack<SwF2>(w, img, OC, 0, 0, 0, s);
+            if (!prepacked) rc = launch_sw_pack<SwF2>(w, img, OC, 0, 0, 0, s);
             if (rc) return rc;
             SwFwdEpi<SwF2::SP> epi{y, bias, OC, in_scale, relu};
             return launch_conv_sw<SwF2>(x, gather_idx, img, epi, B * SwF2::SP, s);
         }
-        rc = launch_sw_pack<SwF3>(w, img, OC, 0, 0, 0, s);
+        if (!prepacked) rc = launch_sw_pack<SwF3>(w, img, OC, 0, 0, 0, s);
         if (rc) return rc;
         SwFwdEpi<SwF3::SP> epi{y, bias, OC, in_scale, relu};
         return launch_conv_sw<SwF3>(x, gather_idx, img, epi, B * SwF3::SP, s);
@@ -313,7 +331,7 @@ extern "C" long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, i
 
 extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C,
                                       int H, int W, int OC, int KH, int KW, int S, void* workspace,
-                                      long workspace_bytes, void* stream) {
+                                      long workspace_bytes, int prepacked, void* stream) {
     ACKTR_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
     const bool gather_ok = false;
     CONV_COMMON_CHECKS("conv2d_dgrad");
@@ -330,14 +348,14 @@ extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const flo
         if (geom == GEOM_4S2) hipLaunchKernelGGL((sw_pad_kernel<9, 9, 1>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
         else hipLaunchKernelGGL((sw_pad_kernel<7, 7, 2>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
         ACKTR_LAUNCH_CHECK();
-        int rc;
+        int rc = 0;
         if (geom == GEOM_4S2) {
-            rc = launch_sw_pack<SwD2>(w, img, 4 * C, 1, C, 2, s);
+            if (!prepacked) rc = launch_sw_pack<SwD2>(w, img, 4 * C, 1, C, 2, s);
             if (rc) return rc;
             SwPhase2Epi<10, 10, 20, 20> epi{dx, x_act};
             return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s);
         }
-        rc = launch_sw_pack<SwD3>(w, img, C, 1, C, 1, s);
+        if (!prepacked) rc = launch_sw_pack<SwD3>(w, img, C, 1, C, 1, s);
         if (rc) return rc;
         SwGateEpi<81> epi{dx, x_act, C};
         return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s);
@@ -349,4 +367,42 @@ extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const flo
     if (geom == GEOM_4S2) return DG(4, 4, 2, 9, 9);
     return DG(3, 3, 1, 7, 7);
 #undef DG
+}
+
+/* Weight images of several layers in one launch; see include/acktr_hip.h. */
+extern "C" int acktr_conv2d_pack_weights_f32(const acktr_conv_pack_job* jobs, int count, void* stream) {
+    ACKTR_ARG(jobs && count > 0 && count <= SW_PACK_MAX_JOBS, "conv2d_pack_weights: 1..%d jobs", SW_PACK_MAX_JOBS);
+    SwPackJobs pj;
+    int n = 0;
+    long biggest = 0;
+    for (int i = 0; i < count; ++i) {
+        const acktr_conv_pack_job& jb = jobs[i];
+        ACKTR_ARG(jb.w && jb.workspace && (((uintptr_t)jb.workspace | (uintptr_t)jb.w) & 15) == 0,
+                  "conv2d_pack_weights: job %d: null or unaligned pointer", i);
+        const int geom = geom_of(jb.H, jb.W, jb.KH, jb.KW, jb.S);
+        SwPackJob o{jb.w, (float*)jb.workspace, 0, 0, 0, 0, 0};
+        long img_floats = 0;
+        if (!jb.dgrad) {
+            const long bytes = geom == GEOM_NONE ? 0 : sw_fwd_image_bytes(geom, jb.C, jb.OC);
+            ACKTR_ARG(bytes > 0 && jb.workspace_bytes >= bytes,
+                      "conv2d_pack_weights: job %d is not a stationary-weight forward geometry (or workspace too small)", i);
+            o.kind = geom == GEOM_8S4 ? PK_F1 : geom == GEOM_4S2 ? PK_F2 : PK_F3;
+            o.M = jb.OC;
+            img_floats = bytes / 4;
+        } else {
+            ACKTR_ARG(geom != GEOM_NONE && sw_dgrad_ok(geom, jb.C, jb.OC),
+                      "conv2d_pack_weights: job %d is not a stationary-weight dgrad geometry", i);
+            img_floats = sw_dgrad_image_floats(geom, jb.OC);
+            ACKTR_ARG(jb.workspace_bytes >= img_floats * 4, "conv2d_pack_weights: job %d: workspace too small", i);
+            o.mode = 1;
+            o.CX = jb.C;
+            if (geom == GEOM_4S2) { o.kind = PK_D2; o.M = 4 * jb.C; o.SD = 2; }
+            else { o.kind = PK_D3; o.M = jb.C; o.SD = 1; }
+        }
+        if (img_floats > biggest) biggest = img_floats;
+        pj.j[n++] = o;
+    }
+    hipLaunchKernelGGL(sw_pack_multi_kernel, dim3((unsigned)((biggest + 255) / 256), n), dim3(256), 0, (hipStream_t)stream, pj);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
 }

@@ -99,8 +99,8 @@ struct SwGeom {
 //                     Wm = w[oc][cx][py + SD*(KH-1-ky)][px + SD*(KW-1-kx)]               w: [OC][CX][KH*SD][KW*SD]
 // ---------------------------------------------------------------------------------------------------
 template <class G>
-__global__ __launch_bounds__(256) void sw_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ img,
-                                                              int M, int mode, int CX, int SD) {
+__device__ __forceinline__ void sw_pack_body(const float* __restrict__ w, float* __restrict__ img, int M, int mode, int CX,
+                                             int SD) {
     constexpr long n = G::image_floats();
     constexpr int C = G::CH;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -125,6 +125,12 @@ __global__ __launch_bounds__(256) void sw_pack_weights_kernel(const float* __res
         }
         img[i] = v;
     }
+}
+
+template <class G>
+__global__ __launch_bounds__(256) void sw_pack_weights_kernel(const float* __restrict__ w, float* __restrict__ img,
+                                                              int M, int mode, int CX, int SD) {
+    sw_pack_body<G>(w, img, M, mode, CX, SD);
 }
 
 // zero-padded copy dyp[pl][y+P][x+P] = dy[pl][y][x]  (planes OH x OW -> HP x WP); 8 planes per workgroup,

@@ -14,6 +14,7 @@
 namespace acktr {
 
 constexpr int LOSS_THREADS = 256;
+constexpr int LOSS_SINGLE_MAX_B = 1024;     // up to one row per lane of a single 1024-lane workgroup
 constexpr float HALF_LOG_2PI = 0.91893853320467274178f;   // log(sqrt(2*pi))
 
 struct DistEval {
@@ -126,16 +127,17 @@ __device__ __forceinline__ LossTerms algo_terms(float logp, float v, float old_l
 }
 
 // One kernel for all (algo, dist) pairs.  algo: 0 PPO, 1 A2C, 2 ACKTR Fisher.
-template <int DIST, int ALGO>
-__global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_args a, float* partial) {
+// SINGLE: one workgroup of 1024 lanes walks all rows (B <= LOSS_SINGLE_MAX_B) and finishes the sums itself, so the
+// fixed-order finalize launch (~4.5 us as a dependent graph node) disappears on minibatch-sized batches.
+template <int DIST, int ALGO, bool SINGLE>
+__global__ __launch_bounds__(SINGLE ? 1024 : LOSS_THREADS) void policy_loss_kernel(acktr_loss_args a, float* partial) {
     __shared__ float sm[16];
-    const int b = blockIdx.x * LOSS_THREADS + threadIdx.x;
     const int A = a.A;
     float vl = 0.f, al = 0.f, en = 0.f;
     const int NP = 3 + (DIST == 1 ? A : 0);
     float dls[DIST == 1 ? 16 : 1];
     if (DIST == 1) for (int j = 0; j < 16; ++j) dls[j] = 0.f;
-    if (b < a.B) {
+    for (int b = blockIdx.x * (int)blockDim.x + threadIdx.x; b < a.B; b += SINGLE ? 1024 : a.B) {
         const long src = a.gather_idx ? (long)a.gather_idx[b] : (long)b;
         const float v = a.values[(long)b * a.ld_values];
         const float* din = a.dist_in + (long)b * a.ld_dist;
@@ -156,10 +158,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_ar
         const float ret = a.returns ? a.returns[src] : 0.f;
         const float advn = a.adv ? a.adv[src] : 0.f;          // advantage (PPO) or Fisher noise (ACKTR)
         const LossTerms t = algo_terms<ALGO>(d.logp, v, o_logp, o_val, ret, advn, a.clip, a.use_clipped_value_loss);
-        vl = t.vl; al = t.al;
+        vl += t.vl; al += t.al;
         const float dlogp = t.dlogp * a.inv_batch;
         const float dv = ((ALGO == 2) ? 1.0f : a.value_coef) * t.dv * a.inv_batch;
-        en = d.ent;
+        en += d.ent;
         // entropy enters the loss as  -entropy_coef * mean(entropy)   (not in the Fisher loss)
         const float dent = (ALGO == 2) ? 0.f : -a.entropy_coef * a.inv_batch;
         if (a.dvalues) a.dvalues[(long)b * a.ld_dvalues] = dv;
@@ -171,13 +173,25 @@ __global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_ar
                 const float sd = expf(a.logstd[j]);
                 const float var = sd * sd, dj = act_f[j] - din[j];
                 dd[j] = dlogp * dj / var;
-                dls[j] = dlogp * (dj * dj / var - 1.f) + dent;
-                if (a.dlogstd_rows) a.dlogstd_rows[(long)b * A + j] = dls[j];
+                const float g = dlogp * (dj * dj / var - 1.f) + dent;
+                dls[j] += g;
+                if (a.dlogstd_rows) a.dlogstd_rows[(long)b * A + j] = g;
             }
         }
     }
     float* out = partial + (long)blockIdx.x * NP;
     float r;
+    if (SINGLE) {
+        r = block_sum(vl, sm); if (threadIdx.x == 0 && a.loss_acc) a.loss_acc[0] += r * a.inv_batch;
+        r = block_sum(al, sm); if (threadIdx.x == 0 && a.loss_acc) a.loss_acc[1] += r * a.inv_batch;
+        r = block_sum(en, sm); if (threadIdx.x == 0 && a.loss_acc) a.loss_acc[2] += r * a.inv_batch;
+        if (DIST == 1)
+            for (int j = 0; j < A; ++j) {
+                r = block_sum(dls[j], sm);
+                if (threadIdx.x == 0) a.dlogstd[j] = r;
+            }
+        return;
+    }
     r = block_sum(vl, sm); if (threadIdx.x == 0) out[0] = r;
     r = block_sum(al, sm); if (threadIdx.x == 0) out[1] = r;
     r = block_sum(en, sm); if (threadIdx.x == 0) out[2] = r;
@@ -276,7 +290,12 @@ extern "C" int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream) 
     hipStream_t s = (hipStream_t)stream;
     const int nblk = cdiv(a.B, LOSS_THREADS);
     float* partial = (float*)a.workspace;
-#define LAUNCH_LOSS(D, G) hipLaunchKernelGGL((policy_loss_kernel<D, G>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial)
+    const bool single = a.B <= LOSS_SINGLE_MAX_B;
+#define LAUNCH_LOSS(D, G)                                                                                           \
+    do {                                                                                                            \
+        if (single) hipLaunchKernelGGL((policy_loss_kernel<D, G, true>), dim3(1), dim3(1024), 0, s, a, partial);     \
+        else hipLaunchKernelGGL((policy_loss_kernel<D, G, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial); \
+    } while (0)
     if (a.dist == 0) {
         if (a.algo == 0) LAUNCH_LOSS(0, 0); else if (a.algo == 1) LAUNCH_LOSS(0, 1); else LAUNCH_LOSS(0, 2);
     } else {
@@ -284,6 +303,7 @@ extern "C" int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream) 
     }
 #undef LAUNCH_LOSS
     ACKTR_LAUNCH_CHECK();
+    if (single) return 0;
     const int NP = 3 + (a.dist == 1 ? a.A : 0);
     hipLaunchKernelGGL(policy_loss_finalize_kernel, dim3(1), dim3(64), 0, s, partial, nblk, NP, a.inv_batch, a.loss_acc,
                        a.dist == 1 ? a.dlogstd : (float*)nullptr);

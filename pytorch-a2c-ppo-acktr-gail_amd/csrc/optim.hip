@@ -16,8 +16,11 @@ namespace acktr {
 constexpr int OPT_THREADS = 256;
 constexpr int OPT_MAX_PARTIALS = 1024;
 
-__global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const float* g, long n, double* partial) {
+// `bump` (optional): the device-side Adam step counter, incremented here by one lane so that the update kernel that
+// follows reads the new value without a launch of its own (a dependent launch costs ~4.5 us inside a hipGraph).
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const float* g, long n, double* partial, int* bump) {
     __shared__ double sm[16];
+    if (bump && blockIdx.x == 0 && threadIdx.x == 0) *bump = *bump + 1;
     double s = 0.0;
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
         const double x = (double)g[i];
@@ -158,7 +161,7 @@ extern "C" int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, 
     const int use_clip = max_grad_norm > 0.f;
     const int nb = grid_for(n);
     if (use_clip) {
-        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace, (int*)nullptr);
         ACKTR_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
@@ -176,10 +179,11 @@ extern "C" int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_a
     hipStream_t s = (hipStream_t)stream;
     const int use_clip = max_grad_norm > 0.f;
     const int nb = grid_for(n);
-    hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
-    ACKTR_LAUNCH_CHECK();
     if (use_clip) {
-        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace, step_dev);
+        ACKTR_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(bump_step_kernel, dim3(1), dim3(1), 0, s, step_dev);
         ACKTR_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
@@ -198,7 +202,7 @@ extern "C" int acktr_clip_rmsprop_f32(float* params, float* grads, float* square
     const int use_clip = max_grad_norm > 0.f;
     const int nb = grid_for(n);
     if (use_clip) {
-        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace);
+        hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace, (int*)nullptr);
         ACKTR_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL((clip_update_kernel<1>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, square_avg,

@@ -284,13 +284,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-side-metrics', action='store_true')
+    ap.add_argument('--force-dp', action='store_true',
+                    help='one rank, but through the data-parallel code path on RCCL (rehearsal of the N>1 path)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world > 1:
+    if world > 1 or args.force_dp:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
@@ -302,6 +305,9 @@ def main():
     N_global = PROCS_PER_GPU * world
     ro = synth_rollouts(T_STEPS, N_global, device, seed=1234)
     pol, agent = build_agent(device, seed=7)
+    if args.force_dp:
+        from a2c_ppo_acktr.parallel import DataParallel
+        agent.dp = DataParallel(force_active=True)
     rs = fill_storage(ro, device)
     rs.compute_returns(ro['next_value'], True, 0.99, 0.95, True)
 
@@ -394,7 +400,7 @@ def main():
             cb1['value'] = round(cb1['value'], 1)
             out['cpu_baseline_1thread'] = cb1
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_dp:
         dist.barrier()
         dist.destroy_process_group()
 

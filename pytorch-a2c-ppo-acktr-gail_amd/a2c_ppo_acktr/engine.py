@@ -236,9 +236,25 @@ def seed_ptrs(acts):
     return acts.dv.data_ptr(), 1, acts.dmean.data_ptr(), acts.dmean.shape[1]
 
 
-def backward(policy, acts, gflat, keep=False, wgrad=True):
+def late_bucket_offset(policy):
+    """Flat-buffer offset that splits the NatureCNN gradient into [conv1, conv2 | conv3, fc, head]: the right part
+    (97 % of the bytes) is complete after `backward(..., phase=1)`, so a data-parallel caller can start its
+    all-reduce while phase 2 (conv3 dgrad, conv2, conv1) still runs.  None when the policy has no such split."""
+    if not is_cnn(policy) or policy.is_recurrent:
+        return None
+    L = cnn_layer_params(policy)
+    off = policy._offsets[id(L['conv3'][0])][0]
+    for name in ('conv1', 'conv2'):
+        for p in L[name]:
+            if policy._offsets[id(p)][0] >= off:
+                return None
+    return off
+
+
+def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None):
     """Parameter gradients of one batch into the flat gradient buffer `gflat` (overwrites, never
-    accumulates).  With keep=True the pre-activation gradients of every layer stay on `acts`
+    accumulates).  phase (NatureCNN only): None = everything; 1 = head, FC and conv3 gradients (everything at or
+    behind late_bucket_offset()); 2 = the rest, continuing from what phase 1 left on `acts`.  With keep=True the pre-activation gradients of every layer stay on `acts`
     (dy1, dy2, dy3, dfeat / dhc*, dha*) -- the `grad_output`s KFAC's backward hooks would see.
     wgrad=False runs the data-gradient chain only (the sampled-Fisher pass of ACKTR needs no
     parameter gradients, a2c_acktr.py:66-70).
@@ -251,19 +267,25 @@ def backward(policy, acts, gflat, keep=False, wgrad=True):
         L = cnn_layer_params(policy)
         wh, _ = head_views(policy, policy.flat_params)
         w3, w2, w1 = L['conv3'][0], L['conv2'][0], L['conv1'][0]
-        if wgrad:
-            gwh, gbh = head_views(policy, gflat)
-            ops.linear_wgrad(acts.dhead, acts.head_in, gwh, gbh)
-        if policy.is_recurrent:
-            dgru = ops.linear_dgrad(acts.dhead, wh)
-            dfeat = gru_backward(policy, acts, dgru, gflat, wgrad=wgrad, dx_gate_src=acts.feat, dx_gate='relu')
+        if phase != 2:
+            if wgrad:
+                gwh, gbh = head_views(policy, gflat)
+                ops.linear_wgrad(acts.dhead, acts.head_in, gwh, gbh)
+            if policy.is_recurrent:
+                dgru = ops.linear_dgrad(acts.dhead, wh)
+                dfeat = gru_backward(policy, acts, dgru, gflat, wgrad=wgrad, dx_gate_src=acts.feat, dx_gate='relu')
+            else:
+                dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
+            if wgrad:
+                ops.linear_wgrad(dfeat, acts.flat3, gv(L['fc'][0]), gv(L['fc'][1]).view(-1))
+            dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
+            if wgrad:
+                ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
+            if phase == 1:
+                acts.dfeat, acts.dy3 = dfeat, dy3
+                return
         else:
-            dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
-        if wgrad:
-            ops.linear_wgrad(dfeat, acts.flat3, gv(L['fc'][0]), gv(L['fc'][1]).view(-1))
-        dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
-        if wgrad:
-            ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
+            dfeat, dy3 = acts.dfeat, acts.dy3
         dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1, packed=acts.packs.get('d3'))
         if wgrad:
             ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1))

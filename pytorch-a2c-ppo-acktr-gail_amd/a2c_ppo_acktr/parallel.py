@@ -12,8 +12,11 @@ import torch.distributed as dist
 
 
 class DataParallel(object):
-    def __init__(self, group=None):
+    def __init__(self, group=None, force_active=False):
+        """force_active: take the data-parallel code path (sharding arithmetic, collectives) even with one rank --
+        lets a one-GPU box drive the real RCCL calls."""
         self.group = group
+        self._force = force_active
         if dist.is_available() and dist.is_initialized():
             self.world = dist.get_world_size(group)
             self.rank = dist.get_rank(group)
@@ -22,11 +25,11 @@ class DataParallel(object):
         # gloo is a host transport: device buckets are staged through host memory here, synchronously, instead of
         # through gloo's own device path (which was seen to hang when two ranks share one GPU, the only way a one-GPU
         # box can rehearse world_size 2).  RCCL ("nccl") reduces the device bucket in place, stream-ordered.
-        self._host_staged = self.world > 1 and dist.get_backend(group) == 'gloo'
+        self._host_staged = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'gloo'
 
     @property
     def active(self):
-        return self.world > 1
+        return self.world > 1 or self._force
 
     def bounds(self, n):
         """Contiguous balanced split of n items: [lo, hi) of this rank."""
@@ -50,6 +53,17 @@ class DataParallel(object):
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
 
+    def all_reduce_sum_async_(self, flat):
+        """Start the SUM all-reduce of a bucket and return a handle whose .wait() orders the current stream after it.
+        RCCL runs it on its own stream, so kernels launched meanwhile overlap with the transfer; the host-staged
+        gloo form (CPU tests, one-GPU rehearsals) simply finishes it here."""
+        if not self.active:
+            return _Done()
+        if self._host_staged and flat.is_cuda:
+            self.all_reduce_sum_(flat)
+            return _Done()
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
     def broadcast_(self, t, src):
         if self.active:
             if self._host_staged and t.is_cuda:
@@ -59,6 +73,11 @@ class DataParallel(object):
             else:
                 dist.broadcast(t, src=src, group=self.group)
         return t
+
+
+class _Done(object):
+    def wait(self):
+        return True
 
 
 def assign_eig_owners(sizes, world):

@@ -14,7 +14,7 @@
 namespace acktr {
 
 constexpr int LOSS_THREADS = 256;
-constexpr int LOSS_SINGLE_MAX_B = 1024;     // up to one row per lane of a single 1024-lane workgroup
+constexpr int LOSS_SINGLE_MAX_B = 256;      // one workgroup covers the batch: it finishes the sums itself
 constexpr float HALF_LOG_2PI = 0.91893853320467274178f;   // log(sqrt(2*pi))
 
 struct DistEval {
@@ -127,17 +127,18 @@ __device__ __forceinline__ LossTerms algo_terms(float logp, float v, float old_l
 }
 
 // One kernel for all (algo, dist) pairs.  algo: 0 PPO, 1 A2C, 2 ACKTR Fisher.
-// SINGLE: one workgroup of 1024 lanes walks all rows (B <= LOSS_SINGLE_MAX_B) and finishes the sums itself, so the
-// fixed-order finalize launch (~4.5 us as a dependent graph node) disappears on minibatch-sized batches.
+// SINGLE: the batch fits one workgroup (B <= LOSS_SINGLE_MAX_B: the MLP / A2C configurations), which then finishes the
+// sums itself and the fixed-order finalize launch disappears.  (One 1024-lane workgroup for B = 1024 was measured
+// slower than four workgroups + finalize: 14.8 us against 9.2 + 4.6.)
 template <int DIST, int ALGO, bool SINGLE>
-__global__ __launch_bounds__(SINGLE ? 1024 : LOSS_THREADS) void policy_loss_kernel(acktr_loss_args a, float* partial) {
+__global__ __launch_bounds__(LOSS_THREADS) void policy_loss_kernel(acktr_loss_args a, float* partial) {
     __shared__ float sm[16];
     const int A = a.A;
     float vl = 0.f, al = 0.f, en = 0.f;
     const int NP = 3 + (DIST == 1 ? A : 0);
     float dls[DIST == 1 ? 16 : 1];
     if (DIST == 1) for (int j = 0; j < 16; ++j) dls[j] = 0.f;
-    for (int b = blockIdx.x * (int)blockDim.x + threadIdx.x; b < a.B; b += SINGLE ? 1024 : a.B) {
+    for (int b = blockIdx.x * (int)blockDim.x + threadIdx.x; b < a.B; b += a.B) {
         const long src = a.gather_idx ? (long)a.gather_idx[b] : (long)b;
         const float v = a.values[(long)b * a.ld_values];
         const float* din = a.dist_in + (long)b * a.ld_dist;
@@ -293,7 +294,7 @@ extern "C" int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream) 
     const bool single = a.B <= LOSS_SINGLE_MAX_B;
 #define LAUNCH_LOSS(D, G)                                                                                           \
     do {                                                                                                            \
-        if (single) hipLaunchKernelGGL((policy_loss_kernel<D, G, true>), dim3(1), dim3(1024), 0, s, a, partial);     \
+        if (single) hipLaunchKernelGGL((policy_loss_kernel<D, G, true>), dim3(1), dim3(LOSS_THREADS), 0, s, a, partial); \
         else hipLaunchKernelGGL((policy_loss_kernel<D, G, false>), dim3(nblk), dim3(LOSS_THREADS), 0, s, a, partial); \
     } while (0)
     if (a.dist == 0) {

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, algo_name):
+def _worker(rank, world, port, out_dir, algo_name, backend='gloo'):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     for p in (os.path.dirname(here), os.path.join(os.path.dirname(here), 'pytorch-a2c-ppo-acktr-gail_amd'), here,
@@ -34,11 +34,13 @@ def _worker(rank, world, port, out_dir, algo_name):
     from helpers import t
     from test_policy_gpu import Discrete, make_storage
     import datetime
-    if world > 1:
+    torch.cuda.set_device(0)
+    if world > 1 or backend == 'nccl':
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
-        dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
-    torch.cuda.set_device(0)
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        kw = dict(device_id=torch.device('cuda', 0)) if backend == 'nccl' else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60), **kw)
     from a2c_ppo_acktr import algo
     from a2c_ppo_acktr.model import Policy
     T, N, A = 6, 12, 6                                   # 72 samples: minibatches of 36 -> shards of 18
@@ -65,6 +67,11 @@ def _worker(rank, world, port, out_dir, algo_name):
         agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
         agent.optimizer.Tf = 2
         n_upd = 3
+    if backend == 'nccl':                                # one rank, but through the data-parallel code path on RCCL
+        from a2c_ppo_acktr.parallel import DataParallel
+        agent.dp = DataParallel(force_active=True)
+        if hasattr(agent.optimizer, 'dp'):
+            agent.optimizer.dp = agent.dp
     losses = []
     for it in range(n_upd):
         torch.manual_seed(40 + it)                       # same CPU stream on every rank: permutation and Fisher noise
@@ -73,8 +80,8 @@ def _worker(rank, world, port, out_dir, algo_name):
     torch.cuda.synchronize()
     if rank == 0:
         torch.save({'flat': pol.flat_params.detach().cpu(), 'losses': torch.tensor(losses, dtype=torch.float64)},
-                   os.path.join(out_dir, '%s_w%d.pt' % (algo_name, world)))
-    if world > 1:
+                   os.path.join(out_dir, '%s_w%d%s.pt' % (algo_name, world, '_rccl' if backend == 'nccl' else '')))
+    if world > 1 or backend == 'nccl':
         dist.barrier()
         dist.destroy_process_group()
 
@@ -86,6 +93,21 @@ def test_two_rank_update_matches_single_process(tmp_path, algo_name):
     mp.spawn(_worker, args=(2, _free_port(), out, algo_name), nprocs=2, join=True)
     one = torch.load(os.path.join(out, '%s_w1.pt' % algo_name))
     two = torch.load(os.path.join(out, '%s_w2.pt' % algo_name))
+    np.testing.assert_allclose(two['losses'].numpy(), one['losses'].numpy(), rtol=2e-4, atol=1e-6)
+    err = float((two['flat'] - one['flat']).norm() / one['flat'].norm())
+    assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err
+
+
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr'])
+def test_rccl_collectives_single_rank(tmp_path, algo_name):
+    """The data-parallel code path on the REAL RCCL backend (one rank is all a one-GPU box can host): split graphs,
+    the asynchronous late-bucket all-reduce on RCCL's stream, factor / eigen all-reduces.  With one rank every
+    collective is an identity, so the result must equal the plain single-process update."""
+    out = str(tmp_path)
+    mp.spawn(_worker, args=(1, 0, out, algo_name), nprocs=1, join=True)
+    mp.spawn(_worker, args=(1, _free_port(), out, algo_name, 'nccl'), nprocs=1, join=True)
+    one = torch.load(os.path.join(out, '%s_w1.pt' % algo_name))
+    two = torch.load(os.path.join(out, '%s_w1_rccl.pt' % algo_name))
     np.testing.assert_allclose(two['losses'].numpy(), one['losses'].numpy(), rtol=2e-4, atol=1e-6)
     err = float((two['flat'] - one['flat']).norm() / one['flat'].norm())
     assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err

@@ -358,10 +358,17 @@ def main():
         gemm_ms = sum(v['total_ms'] for v in prof.values())
         gemm_flop = sum(v['flops_per_call'] * v['calls'] for v in prof.values())
         roof = None
+        traffic, traffic_src = None, None
+        try:      # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py)
+            tp = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic_v3.json')
+            traffic = json.load(open(tp))[dom[0]]['traffic_bytes']
+            traffic_src = 'profiles/r1_pmc_traffic_v3.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)'
+        except Exception:
+            pass
         if dom[0] is not None:
             ach = dom[1]['flops_per_call'] / (dom[1]['avg_ms'] * 1e-3) / 1e12
             roof = dict(bound='mfma', kernel=dom[0], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
-                        unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                        unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=traffic, traffic_source=traffic_src,
                         avg_launch_ms=round(dom[1]['avg_ms'], 4), flop_per_launch=dom[1]['flops_per_call'])
         out = dict(metric='PPO update samples/sec (NatureCNN 84x84x4)', value=round(value, 1), unit='samples/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / args.steps * 1e3, 3),

@@ -1,0 +1,29 @@
+"""HBM-side traffic per launch of the update path's GEMM-class kernels from two rocprofv3 --pmc passes
+(FETCH_SIZE, WRITE_SIZE; KiB per dispatch, summed per kernel by tools/pmc_summary.py).
+
+    python tools/pmc_traffic.py fetch.summary.csv write.summary.csv out.json
+
+Correction per /opt/skills/guides/MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE tallies 128-byte requests at 64
+bytes, so it is doubled; WRITE_SIZE is taken as is.  bench.py reads the JSON for `roofline.traffic`."""
+import csv, json, sys
+OPS = [('conv8s4_fwd', 'SwGeom<8, 8, 4, 84, 84, 4,'), ('conv4s2_fwd', 'SwGeom<4, 4, 2, 20, 20, 32,'),
+       ('conv3s1_fwd', 'SwGeom<3, 3, 1, 9, 9, 64,'), ('conv3s1_dgrad', 'SwGeom<3, 3, 1, 11, 11, 32,'),
+       ('conv4s2_dgrad', 'SwGeom<2, 2, 1, 11, 11, 64,'), ('conv8s4_wgrad', 'ConvOutKC<400>'),
+       ('conv4s2_wgrad', 'ConvOutKC<81>'), ('conv3s1_wgrad', 'ConvOutPos<7, 7, 8>'),
+       ('linear1568x512_fwd', 'DenseKCT<true>, acktr::DenseKCT<true>'),
+       ('linear1568x512_wgrad', 'DenseRCT<true>, acktr::DenseRCT<true>'),
+       ('linear1568x512_dgrad', 'DenseKCT<true>, acktr::DenseRCT<true>')]
+f = {r['kernel']: r for r in csv.DictReader(open(sys.argv[1]))}
+w = {r['kernel']: r for r in csv.DictReader(open(sys.argv[2]))}
+out = {}
+for op, pat in OPS:
+    ks = [k for k in f if pat in k and ('conv_sw_kernel' in k or 'gemm_mfma' in k)]
+    if len(ks) != 1:
+        continue
+    k = ks[0]
+    fk = float(f[k]['FETCH_SIZE']) / int(f[k]['dispatches'])
+    wk = float(w[k]['WRITE_SIZE']) / int(w[k]['dispatches'])
+    out[op] = dict(kernel=k[:160], launches=int(f[k]['dispatches']), fetch_size_kib_raw=round(fk, 1),
+                   write_size_kib=round(wk, 1), traffic_bytes=round((2 * fk + wk) * 1024))
+json.dump(out, open(sys.argv[3], 'w'), indent=1)
+print(json.dumps({k: v['traffic_bytes'] for k, v in out.items()}))

@@ -264,6 +264,27 @@ int acktr_gail_returns_moments_f32(const float* reward, const float* masks, int 
 /* gail.py:110: reward[s, :] /= scale[s]. */
 int acktr_gail_scale_rows_f32(float* reward, const float* scale, int S, int N, void* stream);
 
+/* ---- one-launch minibatch step of the MLP policy (model.py:198-229 MLPBase, distributions.py:76-95 DiagGaussian, the
+ * loss blocks of algo/ppo.py:57-81 and algo/a2c_acktr.py:38-51,70-72): forward of both tanh towers and heads, loss with
+ * its backward seeds, every parameter gradient.  One workgroup, everything resident in LDS.  Supported: B <= 64 rows,
+ * hidden 64, IN <= 64, A <= 8, algo 0 (PPO) or 1 (A2C) -- acktr_mlp_fused_step_supported() tells; other shapes use the
+ * per-layer entry points.  Weights w*: [out, in] row major as nn.Linear stores them; g*: where the gradients go
+ * (overwritten); loss operands as in acktr_loss_args (read through gather_idx when given); loss_acc[3] += means. */
+typedef struct acktr_mlp_step_args {
+    const float *wc0, *bc0, *wc2, *bc2, *wa0, *ba0, *wa2, *ba2, *wv, *bv, *wm, *bm, *logstd;
+    float *gwc0, *gbc0, *gwc2, *gbc2, *gwa0, *gba0, *gwa2, *gba2, *gwv, *gbv, *gwm, *gbm, *glogstd;
+    const float* obs;           /* [rows, IN] */
+    const int64_t* gather_idx;  /* nullable, [B] */
+    int B, IN, H, A;
+    int algo;                   /* 0 PPO, 1 A2C */
+    const float *actions, *old_logp, *old_values, *returns, *adv;
+    float clip, value_coef, entropy_coef, inv_batch;
+    int use_clipped_value_loss;
+    float* loss_acc;            /* nullable */
+} acktr_mlp_step_args;
+int acktr_mlp_fused_step_supported(int B, int IN, int H, int A);
+int acktr_mlp_fused_step_f32(const acktr_mlp_step_args* args, void* stream);
+
 /* ---- recurrent bases: the element-wise links of nn.GRU as driven by NNBase._forward_gru (model.py:89-95,111-166).
  * Gate order r, z, n; rows are environments, [N, H] per step; the per-step products gi = x W_ih^T + b_ih and
  * gh = (h*mask) W_hh^T + b_hh come from acktr_linear_fwd_f32.

@@ -34,6 +34,17 @@ class LossArgs(ctypes.Structure):
                 ('dlogstd', c_p), ('dlogstd_rows', c_p), ('logp_out', c_p), ('loss_acc', c_p),
                 ('workspace', c_p), ('workspace_bytes', c_l)]
 
+class MlpStepArgs(ctypes.Structure):
+    """struct acktr_mlp_step_args (include/acktr_hip.h)"""
+    _fields_ = ([(n, c_p) for n in ('wc0', 'bc0', 'wc2', 'bc2', 'wa0', 'ba0', 'wa2', 'ba2', 'wv', 'bv', 'wm', 'bm', 'logstd',
+                                    'gwc0', 'gbc0', 'gwc2', 'gbc2', 'gwa0', 'gba0', 'gwa2', 'gba2', 'gwv', 'gbv', 'gwm', 'gbm',
+                                    'glogstd', 'obs', 'gather_idx')] +
+                [('B', c_i), ('IN', c_i), ('H', c_i), ('A', c_i), ('algo', c_i)] +
+                [(n, c_p) for n in ('actions', 'old_logp', 'old_values', 'returns', 'adv')] +
+                [('clip', c_f), ('value_coef', c_f), ('entropy_coef', c_f), ('inv_batch', c_f),
+                 ('use_clipped_value_loss', c_i), ('loss_acc', c_p)])
+
+
 class ConvPackJob(ctypes.Structure):
     """struct acktr_conv_pack_job (include/acktr_hip.h)"""
     _fields_ = [('w', c_p), ('workspace', c_p), ('workspace_bytes', c_l),
@@ -95,6 +106,8 @@ _PROTOS = {
     'acktr_gail_reward_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'acktr_gail_returns_moments_f32': (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'acktr_gail_scale_rows_f32': (c_i, [c_p, c_p, c_i, c_i, c_p]),
+    'acktr_mlp_fused_step_supported': (c_i, [c_i, c_i, c_i, c_i]),
+    'acktr_mlp_fused_step_f32': (c_i, [ctypes.POINTER(MlpStepArgs), c_p]),
     'acktr_gru_mask_rows_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     'acktr_gru_gates_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'acktr_gru_gates_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),

@@ -109,6 +109,14 @@ class PPO():
         if phase == 2:
             engine.backward(ac, self._acts, ac.flat_grads, phase=2)
             return
+        nrows = b['idx'].numel()
+        if phase is None and b.get('hxs') is None and engine.mlp_fused_ok(ac, nrows):
+            engine.mlp_fused_step(ac, b['obs'], b['idx'], nrows, engine.ALGO_PPO, b['actions'], b['loss_acc'],
+                                  b['inv_batch'], old_logp=b['old_logp'], old_values=b['old_values'],
+                                  returns=b['returns'], adv=b['adv'], clip=self.clip_param,
+                                  value_coef=self.value_loss_coef, entropy_coef=self.entropy_coef,
+                                  use_clipped_value_loss=self.use_clipped_value_loss)
+            return
         acts = engine.forward(ac, b['obs'], gather_idx=b['idx'], rnn_hxs=b.get('hxs'), masks=b.get('masks'))
         engine.policy_loss(ac, acts, engine.ALGO_PPO, b['actions'], b['loss_acc'], b['inv_batch'],
                            old_logp=b['old_logp'], old_values=b['old_values'], returns=b['returns'], adv=b['adv'],

@@ -15,6 +15,7 @@ t*N+n) as one input GEMM for all steps + per step one hidden GEMM and one gate k
 storage.py:127's gathered copies are never made on the NatureCNN path (fused into conv1's loader).
 """
 import ctypes
+import os
 
 import torch
 
@@ -359,6 +360,57 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
     args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     rc = L.acktr_policy_loss_f32(ctypes.byref(args), _hip.cur_stream(dev))
     _hip.check(rc, 'acktr_policy_loss_f32')
+
+
+# ----------------------------------------------------------------------------------------------
+# one-launch MLP minibatch step (csrc/mlp_fused.hip)
+# ----------------------------------------------------------------------------------------------
+FUSED_MLP = os.environ.get('ACKTR_FUSED_MLP', '1') != '0'
+
+
+def mlp_fused_ok(policy, B):
+    """The fused single-workgroup step covers the reference's MuJoCo shape: non-recurrent MLPBase(hidden 64) with a
+    DiagGaussian head, up to 64 rows.  Anything else runs layer by layer."""
+    if not FUSED_MLP or is_cnn(policy) or policy.is_recurrent or ops.profiler is not None:
+        return False
+    b = policy.base
+    if hasattr(b.actor[0], 'add_bias'):            # KFAC's split_bias surgery: ACKTR needs the per-layer activations
+        return False
+    H, IN = b.actor[0].weight.shape
+    return bool(_hip.lib().acktr_mlp_fused_step_supported(int(B), int(IN), int(H), int(policy.dist.num_outputs)))
+
+
+def mlp_fused_step(policy, obs, gather_idx, B, algo, actions, loss_acc, inv_batch, old_logp=None, old_values=None,
+                   returns=None, adv=None, clip=0.0, value_coef=0.0, entropy_coef=0.0, use_clipped_value_loss=True,
+                   gflat=None):
+    """forward + loss + backward of one minibatch in ONE launch; gradients overwrite `gflat` (default flat_grads)."""
+    L = mlp_layer_params(policy)
+    gflat = policy.flat_grads if gflat is None else gflat
+    dev = obs.device
+    if not obs.is_cuda or obs.dtype != f32 or not obs.is_contiguous():
+        raise RuntimeError('policy inputs must be contiguous float32 tensors on the MI355X device')
+    a = _hip.MlpStepArgs()
+    p = lambda t, dt=f32, name='mlp step operand': (None if t is None else _hip.dev_ptr(t, dt, name).value)
+    ls = logstd_param(policy)
+    for k, (w, b) in (('c0', L['c0']), ('c2', L['c2']), ('a0', L['a0']), ('a2', L['a2'])):
+        setattr(a, 'w' + k, p(w.detach())); setattr(a, 'b' + k, p(b.detach()))
+        setattr(a, 'gw' + k, p(policy.grad_view(w, gflat))); setattr(a, 'gb' + k, p(policy.grad_view(b, gflat)))
+    a.wv, a.bv = p(L['critic'][0].detach()), p(L['critic'][1].detach())
+    a.gwv, a.gbv = p(policy.grad_view(L['critic'][0], gflat)), p(policy.grad_view(L['critic'][1], gflat))
+    a.wm, a.bm = p(L['mean'][0].detach()), p(L['mean'][1].detach())
+    a.gwm, a.gbm = p(policy.grad_view(L['mean'][0], gflat)), p(policy.grad_view(L['mean'][1], gflat))
+    a.logstd, a.glogstd = p(ls.detach()), p(policy.grad_view(ls, gflat))
+    a.obs = p(obs)
+    a.gather_idx = p(gather_idx, torch.int64, 'gather_idx')
+    H, IN = L['a0'][0].shape
+    a.B, a.IN, a.H, a.A, a.algo = int(B), int(IN), int(H), int(policy.dist.num_outputs), int(algo)
+    a.actions = p(actions, f32, 'actions')
+    a.old_logp, a.old_values, a.returns, a.adv = p(old_logp), p(old_values), p(returns), p(adv)
+    a.clip, a.value_coef, a.entropy_coef, a.inv_batch = clip, value_coef, entropy_coef, inv_batch
+    a.use_clipped_value_loss = 1 if use_clipped_value_loss else 0
+    a.loss_acc = p(loss_acc)
+    rc = _hip.lib().acktr_mlp_fused_step_f32(ctypes.byref(a), _hip.cur_stream(dev))
+    _hip.check(rc, 'acktr_mlp_fused_step_f32')
 
 
 # ----------------------------------------------------------------------------------------------

@@ -1,0 +1,331 @@
+// One-launch minibatch step of the MLP policy (reference a2c_ppo_acktr/model.py:198-229 MLPBase + distributions.py:76-95
+// DiagGaussian + the loss blocks of algo/ppo.py:57-81 / algo/a2c_acktr.py:38-51,70-72): forward of both tanh towers and
+// the two heads, the PPO / A2C loss with its backward seeds, and every parameter gradient, for a minibatch of up to 64
+// rows -- the reference's MuJoCo configuration (README.md:115: 2048 steps, 32 minibatches of 64).
+//
+// Why one workgroup: at 64 rows the whole step is ~4 MFLOP; run layer by layer it is ~30 dependent launches of
+// ~4.5 us each and nothing else.  Here the parameters (10 k floats), the gathered observations and all activations
+// live in the LDS of one CU (<= 150 KB) and the step is a chain of 64 x 64 x K products on the vector ALUs:
+//   512 threads = one group of 256 per tower; in a group thread (lo = t % 16, hi = t / 16) owns outputs
+//   (slow index hi + 16 i, fast index lo + 16 j), i, j < 4;
+//   lanes of a wave differ in the FAST index first, so every LDS read is either consecutive words (fast operand) or a
+//   broadcast of at most four addresses (slow operand); matrices whose rows are indexed by lanes have odd pitches.
+// The backward overwrites activations in place (dh2 over h2, dh1 over h1), so no further LDS is needed.
+// Gradients are written straight into the caller's flat gradient buffer (overwrite, like the layer kernels).
+#include "loss_terms.hpp"
+#include "../../include/acktr_hip.h"
+
+namespace acktr {
+
+constexpr int MF_ROWS = 64;       // rows per step (padded with zero rows)
+constexpr int MF_H = 64;          // hidden width (MLPBase default, model.py:199)
+constexpr int MF_MAX_IN = 64;
+constexpr int MF_MAX_A = 8;
+constexpr int MF_PH = 65;         // pitch of [64 x 64] matrices in LDS (odd: rows indexed by lanes are conflict-free)
+constexpr int MF_THREADS = 512;   // two groups of 256: one per tower (critic / actor) wherever the towers are independent
+
+// acc[i][j] += sum_k a(hi + 16 i, k) * b(lo + 16 j, k)
+template <class FA, class FB>
+__device__ __forceinline__ void mf_mm(float (&acc)[4][4], const int K, int lo, int hi, FA a, FB b) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < K; ++k) {
+        float av[4], bv[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = a(hi + 16 * i, k);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = b(lo + 16 * j, k);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
+    }
+}
+
+struct MfLds {      // float offsets into the dynamic LDS block
+    int w0c, w0a, w2c, w2a, wv, wm, b0c, b0a, b2c, b2a, bm, x, h1c, h1a, h2c, h2a, dv, dmean, red, total;
+    int pin;        // pitch of the [64 x IN] matrices (odd)
+};
+__host__ __device__ inline MfLds mf_layout(int IN, int A) {
+    MfLds L;
+    L.pin = IN | 1;
+    int o = 0;
+    auto take = [&](int n) { int r = o; o += (n + 3) / 4 * 4; return r; };
+    L.w0c = take(MF_H * L.pin); L.w0a = take(MF_H * L.pin);
+    L.w2c = take(MF_H * MF_PH); L.w2a = take(MF_H * MF_PH);
+    L.wv = take(MF_H); L.wm = take(MF_MAX_A * MF_H);
+    L.b0c = take(MF_H); L.b0a = take(MF_H); L.b2c = take(MF_H); L.b2a = take(MF_H); L.bm = take(MF_MAX_A);
+    L.x = take(MF_ROWS * L.pin);
+    L.h1c = take(MF_ROWS * MF_PH); L.h1a = take(MF_ROWS * MF_PH);
+    L.h2c = take(MF_ROWS * MF_PH); L.h2a = take(MF_ROWS * MF_PH);
+    L.dv = take(MF_ROWS); L.dmean = take(MF_ROWS * MF_MAX_A);
+    L.red = take(64);
+    L.total = o;
+    return L;
+}
+
+template <int ALGO>
+__global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_step_args a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const int tid = threadIdx.x, tw = tid >> 8, t256 = tid & 255, lo = t256 & 15, hi = t256 >> 4;
+    const int IN = a.IN, A = a.A, B = a.B;
+    const MfLds L = mf_layout(IN, A);
+    const int PIN = L.pin;
+
+    // ---- stage 0: parameters and the gathered observation rows into LDS
+    for (int i = tid; i < MF_H * IN; i += MF_THREADS) {
+        const int u = i / IN, k = i - u * IN;
+        sm[L.w0c + u * PIN + k] = a.wc0[i];
+        sm[L.w0a + u * PIN + k] = a.wa0[i];
+    }
+    for (int i = tid; i < MF_H * MF_H; i += MF_THREADS) {
+        const int u = i >> 6, k = i & 63;
+        sm[L.w2c + u * MF_PH + k] = a.wc2[i];
+        sm[L.w2a + u * MF_PH + k] = a.wa2[i];
+    }
+    for (int i = tid; i < A * MF_H; i += MF_THREADS) sm[L.wm + i] = a.wm[i];
+    if (tid < MF_H) {
+        sm[L.wv + tid] = a.wv[tid];
+        sm[L.b0c + tid] = a.bc0[tid]; sm[L.b0a + tid] = a.ba0[tid];
+        sm[L.b2c + tid] = a.bc2[tid]; sm[L.b2a + tid] = a.ba2[tid];
+        if (tid < A) sm[L.bm + tid] = a.bm[tid];
+    }
+    for (int i = tid; i < MF_ROWS * IN; i += MF_THREADS) {
+        const int r = i / IN, k = i - r * IN;
+        float v = 0.f;
+        if (r < B) {
+            const long src = a.gather_idx ? (long)a.gather_idx[r] : (long)r;
+            v = a.obs[src * IN + k];
+        }
+        sm[L.x + r * PIN + k] = v;
+    }
+    __syncthreads();
+
+    float acc[4][4];
+    // ---- stage 1: h1 = tanh(x W0^T + b0), both towers        (model.py:208-216,226-227)
+    {
+        const float* W = sm + (tw ? L.w0a : L.w0c);
+        const float* bias = sm + (tw ? L.b0a : L.b0c);
+        float* H = sm + (tw ? L.h1a : L.h1c);
+        const float* X = sm + L.x;
+        mf_mm(acc, IN, lo, hi, [&](int r, int k) { return X[r * PIN + k]; }, [&](int u, int k) { return W[u * PIN + k]; });
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) H[(hi + 16 * i) * MF_PH + lo + 16 * j] = tanhf(acc[i][j] + bias[lo + 16 * j]);
+    }
+    __syncthreads();
+    // ---- stage 2: h2 = tanh(h1 W2^T + b2)
+    {
+        const float* W = sm + (tw ? L.w2a : L.w2c);
+        const float* bias = sm + (tw ? L.b2a : L.b2c);
+        const float* H1 = sm + (tw ? L.h1a : L.h1c);
+        float* H2 = sm + (tw ? L.h2a : L.h2c);
+        mf_mm(acc, MF_H, lo, hi, [&](int r, int k) { return H1[r * MF_PH + k]; }, [&](int u, int k) { return W[u * MF_PH + k]; });
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) H2[(hi + 16 * i) * MF_PH + lo + 16 * j] = tanhf(acc[i][j] + bias[lo + 16 * j]);
+    }
+    __syncthreads();
+    // ---- stage 3: heads, distribution, loss and its seeds -- one lane per row (wave 0)
+    if (tid < MF_ROWS) {
+        const int r = tid;
+        const float* h2c = sm + L.h2c + r * MF_PH;
+        const float* h2a = sm + L.h2a + r * MF_PH;
+        float v = 0.f;
+        for (int u = 0; u < MF_H; ++u) v = __builtin_fmaf(h2c[u], sm[L.wv + u], v);
+        v += a.bv[0];
+        float mean[MF_MAX_A];
+#pragma unroll
+        for (int j = 0; j < MF_MAX_A; ++j) {
+            float m = 0.f;
+            if (j < A) {
+                for (int u = 0; u < MF_H; ++u) m = __builtin_fmaf(h2a[u], sm[L.wm + j * MF_H + u], m);
+                m += sm[L.bm + j];
+            }
+            mean[j] = m;
+        }
+        float vl = 0.f, al = 0.f, en = 0.f, dv = 0.f;
+        float dls[MF_MAX_A], dm[MF_MAX_A];
+#pragma unroll
+        for (int j = 0; j < MF_MAX_A; ++j) { dls[j] = 0.f; dm[j] = 0.f; }
+        if (r < B) {
+            const long src = a.gather_idx ? (long)a.gather_idx[r] : (long)r;
+            const float* act = a.actions + src * A;
+            float actv[MF_MAX_A];
+#pragma unroll
+            for (int j = 0; j < MF_MAX_A; ++j) actv[j] = j < A ? act[j] : 0.f;
+            const DistEval d = gaussian_eval(mean, a.logstd, actv, A);
+            const float o_logp = a.old_logp ? a.old_logp[src] : 0.f;
+            const float o_val = a.old_values ? a.old_values[src] : 0.f;
+            const float ret = a.returns ? a.returns[src] : 0.f;
+            const float advn = a.adv ? a.adv[src] : 0.f;
+            const LossTerms t = algo_terms<ALGO>(d.logp, v, o_logp, o_val, ret, advn, a.clip, a.use_clipped_value_loss);
+            vl = t.vl; al = t.al; en = d.ent;
+            const float dlogp = t.dlogp * a.inv_batch;
+            dv = a.value_coef * t.dv * a.inv_batch;
+            const float dent = -a.entropy_coef * a.inv_batch;
+#pragma unroll
+            for (int j = 0; j < MF_MAX_A; ++j) {
+                if (j < A) {
+                    const float sd = expf(a.logstd[j]);
+                    const float var = sd * sd, dj = actv[j] - mean[j];
+                    dm[j] = dlogp * dj / var;
+                    dls[j] = dlogp * (dj * dj / var - 1.f) + dent;
+                }
+            }
+        }
+        sm[L.dv + r] = dv;
+#pragma unroll
+        for (int j = 0; j < MF_MAX_A; ++j) sm[L.dmean + r * MF_MAX_A + j] = dm[j];
+        // wave 0 holds all 64 rows: fixed-order wave sums
+        const float svl = wave_sum(vl), sal = wave_sum(al), sen = wave_sum(en), sdv = wave_sum(dv);
+        if (tid == 0) {
+            if (a.loss_acc) {
+                a.loss_acc[0] += svl * a.inv_batch;
+                a.loss_acc[1] += sal * a.inv_batch;
+                a.loss_acc[2] += sen * a.inv_batch;
+            }
+            a.gbv[0] = sdv;
+        }
+#pragma unroll
+        for (int j = 0; j < MF_MAX_A; ++j) {
+            if (j < A) {                                         // uniform
+                const float s1 = wave_sum(dls[j]), s2 = wave_sum(dm[j]);
+                if (tid == 0) { a.glogstd[j] = s1; a.gbm[j] = s2; }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- stage 4a: head weight gradients (h2 still holds activations)
+    if (tid < MF_H) {
+        const int u = tid;
+        float g = 0.f;
+        for (int r = 0; r < MF_ROWS; ++r) g = __builtin_fmaf(sm[L.dv + r], sm[L.h2c + r * MF_PH + u], g);
+        a.gwv[u] = g;
+    }
+    for (int i = tid; i < A * MF_H; i += MF_THREADS) {
+        const int j = i >> 6, u = i & 63;
+        float g = 0.f;
+        for (int r = 0; r < MF_ROWS; ++r) g = __builtin_fmaf(sm[L.dmean + r * MF_MAX_A + j], sm[L.h2a + r * MF_PH + u], g);
+        a.gwm[i] = g;
+    }
+    __syncthreads();
+    // ---- stage 4b: dh2 = (d head-out W_head) * (1 - h2^2), in place over h2
+    for (int i = tid; i < MF_ROWS * MF_H; i += MF_THREADS) {
+        const int r = i >> 6, u = i & 63;
+        const float hc = sm[L.h2c + r * MF_PH + u];
+        sm[L.h2c + r * MF_PH + u] = (sm[L.dv + r] * sm[L.wv + u]) * (1.f - hc * hc);
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < MF_MAX_A; ++j)
+            if (j < A) s = __builtin_fmaf(sm[L.dmean + r * MF_MAX_A + j], sm[L.wm + j * MF_H + u], s);
+        const float ha = sm[L.h2a + r * MF_PH + u];
+        sm[L.h2a + r * MF_PH + u] = s * (1.f - ha * ha);
+    }
+    __syncthreads();
+    // ---- stage 5: dW2[u][i] = sum_r dh2[r][u] h1[r][i]; db2[u] = sum_r dh2[r][u]
+    {
+        const float* D2 = sm + (tw ? L.h2a : L.h2c);
+        const float* H1 = sm + (tw ? L.h1a : L.h1c);
+        float* gw = tw ? a.gwa2 : a.gwc2;
+        float* gb = tw ? a.gba2 : a.gbc2;
+        mf_mm(acc, MF_ROWS, lo, hi, [&](int u, int r) { return D2[r * MF_PH + u]; }, [&](int i, int r) { return H1[r * MF_PH + i]; });
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gw[(hi + 16 * i) * MF_H + lo + 16 * j] = acc[i][j];
+        if (t256 < MF_H) {
+            float g = 0.f;
+            for (int r = 0; r < MF_ROWS; ++r) g += D2[r * MF_PH + t256];
+            gb[t256] = g;
+        }
+    }
+    __syncthreads();
+    // ---- stage 6: dh1[r][i] = (sum_u dh2[r][u] W2[u][i]) * (1 - h1[r][i]^2), in place over h1
+    {
+        const float* D2 = sm + (tw ? L.h2a : L.h2c);
+        const float* W = sm + (tw ? L.w2a : L.w2c);
+        float* H1 = sm + (tw ? L.h1a : L.h1c);
+        mf_mm(acc, MF_H, lo, hi, [&](int r, int u) { return D2[r * MF_PH + u]; }, [&](int i, int u) { return W[u * MF_PH + i]; });
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float* p = H1 + (hi + 16 * i) * MF_PH + lo + 16 * j;
+                const float h = *p;
+                *p = acc[i][j] * (1.f - h * h);
+            }
+    }
+    __syncthreads();
+    // ---- stage 7: dW0[u][k] = sum_r dh1[r][u] x[r][k]; db0[u] = sum_r dh1[r][u]
+    {
+        const float* D1 = sm + (tw ? L.h1a : L.h1c);
+        const float* X = sm + L.x;
+        float* gw = tw ? a.gwa0 : a.gwc0;
+        float* gb = tw ? a.gba0 : a.gbc0;
+        mf_mm(acc, MF_ROWS, lo, hi, [&](int u, int r) { return D1[r * MF_PH + u]; },
+              [&](int k, int r) { return k < IN ? X[r * PIN + k] : 0.f; });
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (lo + 16 * j < IN) gw[(hi + 16 * i) * IN + lo + 16 * j] = acc[i][j];
+        if (t256 < MF_H) {
+            float g = 0.f;
+            for (int r = 0; r < MF_ROWS; ++r) g += D1[r * MF_PH + t256];
+            gb[t256] = g;
+        }
+    }
+}
+
+}  // namespace acktr
+
+using namespace acktr;
+
+extern "C" int acktr_mlp_fused_step_supported(int B, int IN, int H, int A) {
+    return B >= 1 && B <= MF_ROWS && H == MF_H && IN >= 1 && IN <= MF_MAX_IN && A >= 1 && A <= MF_MAX_A;
+}
+
+extern "C" int acktr_mlp_fused_step_f32(const acktr_mlp_step_args* args, void* stream) {
+    ACKTR_ARG(args, "mlp_fused_step: null args");
+    const acktr_mlp_step_args& a = *args;
+    ACKTR_ARG(acktr_mlp_fused_step_supported(a.B, a.IN, a.H, a.A),
+              "mlp_fused_step: unsupported shape B=%d IN=%d H=%d A=%d (B <= %d, H == %d, IN <= %d, A <= %d)", a.B, a.IN,
+              a.H, a.A, MF_ROWS, MF_H, MF_MAX_IN, MF_MAX_A);
+    ACKTR_ARG(a.algo == 0 || a.algo == 1, "mlp_fused_step: algo must be 0 (PPO) or 1 (A2C)");
+    ACKTR_ARG(a.wc0 && a.bc0 && a.wc2 && a.bc2 && a.wa0 && a.ba0 && a.wa2 && a.ba2 && a.wv && a.bv && a.wm && a.bm &&
+                  a.logstd, "mlp_fused_step: null parameter pointer");
+    ACKTR_ARG(a.gwc0 && a.gbc0 && a.gwc2 && a.gbc2 && a.gwa0 && a.gba0 && a.gwa2 && a.gba2 && a.gwv && a.gbv && a.gwm &&
+                  a.gbm && a.glogstd, "mlp_fused_step: null gradient pointer");
+    ACKTR_ARG(a.obs && a.actions, "mlp_fused_step: null observations / actions");
+    ACKTR_ARG(a.algo != 0 || (a.old_logp && a.old_values && a.returns && a.adv), "mlp_fused_step: PPO needs rollout arrays");
+    ACKTR_ARG(a.algo != 1 || a.returns, "mlp_fused_step: A2C needs returns");
+    const MfLds L = mf_layout(a.IN, a.A);
+    const int smem = L.total * (int)sizeof(float);
+    ACKTR_ARG(smem <= 160 * 1024, "mlp_fused_step: LDS budget exceeded (%d bytes)", smem);
+    static bool attr_set[2] = {false, false};
+    auto set_attr = [&](const void* fn, int which) -> int {
+        if (attr_set[which]) return 0;
+        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { set_error("mlp_fused_step: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set[which] = true;
+        return 0;
+    };
+    hipStream_t s = (hipStream_t)stream;
+    if (a.algo == 0) {
+        int rc = set_attr(reinterpret_cast<const void*>(mlp_fused_step_kernel<0>), 0);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mlp_fused_step_kernel<0>, dim3(1), dim3(MF_THREADS), smem, s, a);
+    } else {
+        int rc = set_attr(reinterpret_cast<const void*>(mlp_fused_step_kernel<1>), 1);
+        if (rc) return rc;
+        hipLaunchKernelGGL(mlp_fused_step_kernel<1>, dim3(1), dim3(MF_THREADS), smem, s, a);
+    }
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}

@@ -201,3 +201,39 @@ def test_act_and_get_value_shapes():
     pol2 = make_policy('mlp', 11, 3, 4)
     v, a, lp, h = pol2.act(torch.randn(5, 11).cuda(), None, None)
     assert v.shape == (5, 1) and a.shape == (5, 3) and lp.shape == (5, 1)
+
+
+@pytest.mark.parametrize('od,A,B,algo_id', [(11, 3, 64, 0), (17, 6, 37, 0), (64, 8, 64, 1), (5, 1, 1, 0)])
+def test_mlp_fused_step_matches_layer_path(od, A, B, algo_id):
+    """csrc/mlp_fused.hip (one launch) against the per-layer kernels on the same minibatch: loss sums and every
+    gradient, through a gather index, for PPO and A2C and for ragged row counts."""
+    from a2c_ppo_acktr import engine
+    from a2c_ppo_acktr.model import Policy
+    rows = 200
+    P = synth.make_params(shapes_for('mlp', od, A), 90 + od)
+    pol = Policy((od,), Box(A))
+    pol.load_state_dict(OrderedDict((k, t(v)) for k, v in P.items()), strict=True)
+    pol.to('cuda')
+    d = lambda a: t(a).cuda()
+    obs = d(synth.normalish((rows, od), 91))
+    act = d(synth.normalish((rows, A), 92))
+    olp = d((-1.5 + 0.2 * synth.normalish((rows,), 93)).astype(np.float32))
+    ov, ret, adv = d(synth.normalish((rows,), 94)), d(synth.normalish((rows,), 95)), d(synth.normalish((rows,), 96))
+    idx = d(synth.randint((B,), 97, rows))
+    assert engine.mlp_fused_ok(pol, B)
+    kw = dict(old_logp=olp, old_values=ov, returns=ret, adv=adv, clip=0.2, value_coef=0.5, entropy_coef=0.01)
+    if algo_id == 1:
+        kw = dict(returns=ret, value_coef=0.5, entropy_coef=0.01)
+    g_ref = torch.zeros_like(pol.flat_params)
+    l_ref = torch.zeros(3, device='cuda')
+    acts = engine.forward(pol, obs, gather_idx=idx)
+    engine.policy_loss(pol, acts, algo_id, act, l_ref, 1.0 / B, gather_idx=idx, gflat=g_ref, **kw)
+    engine.backward(pol, acts, g_ref)
+    g_fused = torch.full_like(pol.flat_params, 7.0)
+    l_fused = torch.zeros(3, device='cuda')
+    engine.mlp_fused_step(pol, obs, idx, B, algo_id, act, l_fused, 1.0 / B, gflat=g_fused, **kw)
+    np.testing.assert_allclose(l_fused.cpu().numpy(), l_ref.cpu().numpy(), rtol=2e-5, atol=1e-6)
+    for n, p in pol.named_parameters():
+        a_, b_ = pol.grad_view(p, g_fused).cpu().numpy().reshape(-1), pol.grad_view(p, g_ref).cpu().numpy().reshape(-1)
+        err = np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-20)
+        assert err < 2e-5, '%s rel err %g' % (n, err)

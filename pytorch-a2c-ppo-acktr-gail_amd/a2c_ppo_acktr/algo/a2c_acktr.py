@@ -4,6 +4,8 @@ A2C: one full-batch HIP forward, the fused A2C loss kernel, HIP backward, clip-n
 launches.  ACKTR adds the sampled-Fisher backward whose layer inputs / grad-outputs feed the KFAC
 factor kernels, then `KFACOptimizer.step` (algo/kfac.py).
 """
+import os
+
 import torch
 
 from .. import _hip, engine, ops
@@ -61,14 +63,41 @@ class A2C_ACKTR():
         self.dp = DataParallel()
         if acktr:
             self.optimizer.dp = self.dp
+        # hipGraph replay of the whole A2C update (launch-bound at the reference's 80-sample batch): captured at the
+        # second update() that sees the same storage, shapes and hyper-parameters; ACKTR_HIP_GRAPH=0 disables it.
+        self.use_graph = os.environ.get('ACKTR_HIP_GRAPH', '1') != '0'
+        self._graph, self._seen_key, self._loss_acc = None, None, None
 
     def update(self, rollouts):
+        ac = self.actor_critic
+        if self.acktr or self.dp.active or not self.use_graph or ops.profiler is not None:
+            return self._update(rollouts, None)
+        g = self.optimizer.param_groups[0]
+        key = tuple(getattr(rollouts, k).data_ptr() for k in ('obs', 'actions', 'returns', 'masks',
+                                                                'recurrent_hidden_states')) + \
+            (tuple(rollouts.rewards.size()[0:2]), ac.flat_params.data_ptr(), self.value_loss_coef, self.entropy_coef,
+             self.max_grad_norm, g['lr'], g['alpha'], g['eps'])
+        if self._seen_key != key:                   # first sight of this configuration: run it launch by launch
+            self._seen_key, self._graph = key, None
+            self._loss_acc = torch.zeros(3, dtype=torch.float32, device=rollouts.rewards.device)
+            return self._update(rollouts, None)
+        if self._graph is None:
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._update(rollouts, self._loss_acc)
+        self._loss_acc.zero_()
+        self._graph.replay()
+        vl, al, en = self._loss_acc.tolist()
+        return vl, al, en
+
+    def _update(self, rollouts, captured_loss_acc):
         ac = self.actor_critic
         T, N = rollouts.rewards.size()[0:2]
         rows = T * N
         dev = rollouts.rewards.device
         with torch.no_grad():
-            loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
+            capturing = captured_loss_acc is not None
+            loss_acc = captured_loss_acc if capturing else torch.zeros(3, dtype=torch.float32, device=dev)
             obs_flat = rollouts.obs[:T].view(rows, *rollouts.obs.size()[2:])
             actions = rollouts.actions.view(rows, -1)
             returns = rollouts.returns[:T].view(rows)
@@ -90,18 +119,26 @@ class A2C_ACKTR():
             elif self.dp.active:                   # shard the full batch over ranks (rows are independent)
                 lo, hi = self.dp.bounds(rows)
                 idx = torch.arange(lo, hi, device=dev)
-            acts = engine.forward(ac, obs_flat, gather_idx=idx, rnn_hxs=hxs, masks=masks)   # a2c_acktr.py:38-43
-            if self.acktr and self.optimizer.steps % self.optimizer.Ts == 0:
-                self.optimizer.accumulate_stats(acts, actions, idx, inv_batch, self.dp)  # a2c_acktr.py:53-68
-            engine.policy_loss(ac, acts, engine.ALGO_A2C, actions, loss_acc, inv_batch, returns=returns,
-                               gather_idx=idx, value_coef=self.value_loss_coef,
-                               entropy_coef=self.entropy_coef)                          # a2c_acktr.py:48-51,70-72
-            engine.backward(ac, acts, ac.flat_grads)
+            nloc = rows if idx is None else idx.numel()
+            if not self.acktr and hxs is None and engine.mlp_fused_ok(ac, nloc):
+                engine.mlp_fused_step(ac, obs_flat, idx, nloc, engine.ALGO_A2C, actions, loss_acc, inv_batch,
+                                      returns=returns, value_coef=self.value_loss_coef,
+                                      entropy_coef=self.entropy_coef)
+            else:
+                acts = engine.forward(ac, obs_flat, gather_idx=idx, rnn_hxs=hxs, masks=masks)   # a2c_acktr.py:38-43
+                if self.acktr and self.optimizer.steps % self.optimizer.Ts == 0:
+                    self.optimizer.accumulate_stats(acts, actions, idx, inv_batch, self.dp)  # a2c_acktr.py:53-68
+                engine.policy_loss(ac, acts, engine.ALGO_A2C, actions, loss_acc, inv_batch, returns=returns,
+                                   gather_idx=idx, value_coef=self.value_loss_coef,
+                                   entropy_coef=self.entropy_coef)                          # a2c_acktr.py:48-51,70-72
+                engine.backward(ac, acts, ac.flat_grads)
             self.dp.all_reduce_sum_(ac.flat_grads)
             if self.acktr == False:
                 self.optimizer.step(self.max_grad_norm)                                 # a2c_acktr.py:74-78
             else:
                 self.optimizer.step()
+            if capturing:
+                return None
             self.dp.all_reduce_sum_(loss_acc)
             vl, al, en = loss_acc.tolist()
         return vl, al, en

@@ -67,11 +67,53 @@ class A2C_ACKTR():
         # second update() that sees the same storage, shapes and hyper-parameters; ACKTR_HIP_GRAPH=0 disables it.
         self.use_graph = os.environ.get('ACKTR_HIP_GRAPH', '1') != '0'
         self._graph, self._seen_key, self._loss_acc = None, None, None
+        self._kgraphs, self._noise_dev = {}, None
+
+    def _update_acktr_graphed(self, rollouts):
+        """ACKTR update with the launch-bound part replayed from a hipGraph: everything except the steps that
+        eigendecompose (rocSOLVER's host-driven solver cannot be captured) and the first two (one-off initialisation
+        flags).  The Fisher noise keeps coming from the CPU generator (F7): it is drawn before every replay into the
+        buffer the captured loss kernel reads."""
+        ac, opt = self.actor_critic, self.optimizer
+        T, N = rollouts.rewards.size()[0:2]
+        dev = rollouts.rewards.device
+        key = tuple(getattr(rollouts, k).data_ptr() for k in ('obs', 'actions', 'returns')) + \
+            (T, N, ac.flat_params.data_ptr(), self.value_loss_coef, self.entropy_coef, opt.lr, opt.Ts, opt.Tf,
+             opt.damping, opt.kl_clip, opt.stat_decay, opt.momentum, opt.weight_decay)
+        if self._seen_key != key:
+            self._seen_key, self._kgraphs = key, {}
+            self._loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)
+            self._noise_dev = torch.zeros(T * N, 1, dtype=torch.float32, device=dev)
+            return self._update(rollouts, None)
+        do_stats = opt.steps % opt.Ts == 0
+        if opt.steps < 2 or opt.steps % opt.Tf == 0 or opt.weight_decay > 0:
+            return self._update(rollouts, None)
+        g = self._kgraphs.get(do_stats)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            steps0 = opt.steps
+            opt._ext_noise = self._noise_dev
+            try:
+                with torch.cuda.graph(g):
+                    self._update(rollouts, self._loss_acc)
+            finally:
+                opt._ext_noise = None
+                opt.steps = steps0                  # capture only records: the replay below is this update
+            self._kgraphs[do_stats] = g
+        if do_stats:
+            self._noise_dev.copy_(torch.randn(T * N, 1))       # the draw accumulate_stats makes (a2c_acktr.py:59)
+        self._loss_acc.zero_()
+        g.replay()
+        opt.steps += 1
+        vl, al, en = self._loss_acc.tolist()
+        return vl, al, en
 
     def update(self, rollouts):
         ac = self.actor_critic
-        if self.acktr or self.dp.active or not self.use_graph or ops.profiler is not None:
+        if self.dp.active or not self.use_graph or ops.profiler is not None:
             return self._update(rollouts, None)
+        if self.acktr:
+            return self._update_acktr_graphed(rollouts)
         g = self.optimizer.param_groups[0]
         key = tuple(getattr(rollouts, k).data_ptr() for k in ('obs', 'actions', 'returns', 'masks',
                                                                 'recurrent_hidden_states')) + \

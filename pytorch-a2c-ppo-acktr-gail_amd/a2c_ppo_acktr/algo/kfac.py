@@ -106,6 +106,7 @@ class KFACOptimizer(optim.Optimizer):
         self._mom_buf = None
         self._ready_device = None
         self.dp = DataParallel()          # replaced by A2C_ACKTR with its own context
+        self._ext_noise = None
 
     # ------------------------------------------------------------------ module discovery (kfac.py:179-188)
     def _prepare_model(self):
@@ -253,8 +254,11 @@ class KFACOptimizer(optim.Optimizer):
 
         # ---- sampled Fisher loss and its data-gradient chain (a2c_acktr.py:56-68)
         rows_total = Bg
-        noise = torch.randn(rows_total, 1)                        # CPU default generator, like the reference (F7)
-        noise = noise.to(dev, non_blocking=True).view(-1)
+        if self._ext_noise is not None:                           # hipGraph capture: the caller refills this buffer
+            noise = self._ext_noise.view(-1)                      # from the same CPU draw before every replay
+        else:
+            noise = torch.randn(rows_total, 1)                    # CPU default generator, like the reference (F7)
+            noise = noise.to(dev, non_blocking=True).view(-1)
         dls_rows = None
         if not cnn:
             dls_rows = torch.empty(B, pol.dist.num_outputs, dtype=f32, device=dev)

@@ -124,6 +124,14 @@ struct OperandTile {
 //     optional: sum over k of the M operand's rows (the bias gradient of a wgrad GEMM, where the M operand is dY),
 //     accumulated from the registers the loader holds anyway -- dY is not read a second time for it
 // ------------------------------------------------------------------------------------------
+// Symmetric outputs (C = X X^T, the KFAC factors): an epilogue may declare a tile redundant -- every element of it lies
+// strictly below the diagonal; launch_symmetrize_lower() fills the lower triangle from the upper one at the end
+// (mirroring inside the epilogue was tried first: its column-strided stores cost what the skipped tiles saved).
+template <class Epi>
+struct EpiSym {
+    __device__ static __forceinline__ bool skip(const Epi&, int, int, int) { return false; }
+};
+
 template <int BM, int BN, int WM, int WN, class MOp, class NOp, class Epi, bool ZBATCH = false>
 __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const NOp nop, const Epi epi, int K,
                                                             int kchunk) {
@@ -140,6 +148,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    if (EpiSym<Epi>::skip(epi, m0, n0, BN)) return;        // workgroup-uniform, before any barrier
     const int kbeg = ZBATCH ? 0 : blockIdx.z * kchunk;     // ZBATCH: z is a phase index the functors read themselves
     int kend = kbeg + kchunk;
     if (kend > K) kend = K;
@@ -430,6 +439,8 @@ struct RowMajorEpi {
     const float* gate_src; long ldg; int gate; int accumulate;
     const float* div_m; const float* div_n; float div_add;     // v /= (div_m[m]*div_n[n] + div_add)  (KFAC damping)
     float* rowsum_dst; long rowsum_stride;                     // optional: rowsum_dst[slab*stride + m] = sum_k Mop(m, k)
+    int symmetric;                                             // C = X X^T: tiles strictly below the diagonal are skipped;
+                                                               // the caller mirrors the upper triangle afterwards
     static constexpr bool HAS_ROWSUM = true;
     __device__ __forceinline__ bool wants_rowsum() const { return rowsum_dst != nullptr; }
     __device__ __forceinline__ void rowsum(int m, float v, int ks) const {
@@ -454,11 +465,21 @@ struct RowMajorEpi {
         *d = v;
     }
 };
+template <>
+struct EpiSym<RowMajorEpi> {
+    __device__ static __forceinline__ bool skip(const RowMajorEpi& e, int m0, int n0, int BN) {
+        return e.symmetric && m0 > n0 + BN - 1;
+    }
+};
 static inline RowMajorEpi row_major_epi(float* c, int M, int N, long ldc) {
     RowMajorEpi e; e.c = c; e.M = M; e.N = N; e.ldc = ldc; e.slab_stride = 0; e.bias_n = nullptr; e.bias_m = nullptr;
     e.scale = 1.f; e.act = 0; e.gate_src = nullptr; e.ldg = 0; e.gate = 0; e.accumulate = 0;
-    e.div_m = nullptr; e.div_n = nullptr; e.div_add = 0.f; e.rowsum_dst = nullptr; e.rowsum_stride = 0; return e;
+    e.div_m = nullptr; e.div_n = nullptr; e.div_add = 0.f; e.rowsum_dst = nullptr; e.rowsum_stride = 0; e.symmetric = 0;
+    return e;
 }
+
+// c[i][j] = c[j][i] for i > j (square, row major, leading dimension n)
+int launch_symmetrize_lower(float* c, int n, hipStream_t stream);
 
 // Fixed-order slab reduction: dst[i] (=|+=) scale * sum_s slabs[s*stride + i].  With >= 16 slabs it runs in two
 // passes and keeps up to SLAB_GROUP_EXTRA group partials right behind the slabs: size workspaces accordingly.

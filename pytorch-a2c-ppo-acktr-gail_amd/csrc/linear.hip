@@ -169,6 +169,21 @@ int gemm_rowmajor(const float* a, long a_srow, long a_sk, const float* b, long b
     return gemm_rowmajor_t<false>(a, a_srow, a_sk, b, b_srow, b_sk, epi, M, N, K, nslices, s);
 }
 
+__global__ __launch_bounds__(256) void symmetrize_lower_kernel(float* c, int n) {
+    const long total = (long)n * n;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int i = (int)(e / n), j = (int)(e - (long)i * n);
+        if (i > j) c[e] = c[(long)j * n + i];
+    }
+}
+int launch_symmetrize_lower(float* c, int n, hipStream_t stream) {
+    int blocks = cdiv((long)n * n, 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(symmetrize_lower_kernel, dim3(blocks), dim3(256), 0, stream, c, n);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
 int pick_slices(long tiles, long K, long max_by_ws) {
     long want = 768 / (tiles > 0 ? tiles : 1);
     long by_k = K / (4 * GK);              // at least 4 K tiles per slice

@@ -201,3 +201,30 @@ def test_acktr_update_vs_reference(ci):
                                                    lambda n: truth[it]['param:' + unsplit_name(n)])
         print(tag, 'update', it, 'params: e_ref %.3g e_mine %.3g mine-vs-golden %.3g' % (p_ref, p_mine, p_mg))
         assert p_mine <= 4.0 * p_ref + 1e-4 and p_mg <= 1e-3, (it, p_ref, p_mine, p_mg)
+
+
+@pytest.mark.parametrize('ci', range(len(KFAC_CASES)))
+def test_acktr_graph_replay_matches_eager(ci):
+    """The hipGraph-replayed ACKTR update (every step that does not eigendecompose, from the third on) against the
+    same updates launched one by one: same CPU noise stream, same losses, same parameters."""
+    from a2c_ppo_acktr import algo
+    tag, kind, od, A, T, N = KFAC_CASES[ci]
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=820 + ci)
+    out = []
+    for use_graph in (False, True):
+        pol = make_policy(kind, od, A, 90 + ci)
+        rs = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
+        rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
+        agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
+        agent.use_graph = use_graph
+        agent.optimizer.Tf = 4                       # eig at optimizer steps 0 and 4; replays at 2, 3, 5, 6
+        agent.optimizer.lr = 0.02                    # keep seven updates on one rollout well behaved
+        torch.manual_seed(77)
+        losses = [agent.update(rs) for _ in range(7)]
+        if use_graph:
+            assert len(agent._kgraphs) == 1
+        out.append((np.array(losses), pol.flat_params.detach().cpu().numpy().copy()))
+    np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-5, atol=1e-7)
+    err = np.linalg.norm(out[1][1] - out[0][1]) / np.linalg.norm(out[0][1])
+    assert err < 1e-6, err

@@ -244,7 +244,10 @@ __device__ __forceinline__ f32x4 shift_down1(bool cl, const f32x4& v) {
 }
 
 // stride-1 im2col: element (kk = (c,ky,kx), padded position pp = (b, oy, oxp))
-template <int KH, int KW, int H, int W, int OWP, bool INNER_K>
+// ZERO_PAD: the padded position of a row (oxp = OW) reads as an all-zero patch.  Not needed when the other GEMM operand
+// is zero there (wgrad: dY) or the column is never stored (forward); needed when both operands are patches (KFAC's
+// A factor), where the over-read window would otherwise be squared into the result.
+template <int KH, int KW, int H, int W, int OWP, bool INNER_K, bool ZERO_PAD = false>
 struct Im2colPos {
     static constexpr bool INNER_IS_K = INNER_K;          // true: positions are the GEMM K (wgrad); false: rows (fwd)
     static constexpr int OH = H - KH + 1, OW = W - KW + 1, PP = OH * OWP, KK = KH * KW, HW = H * W;
@@ -263,16 +266,19 @@ struct Im2colPos {
         const int pc = in.ok ? p0 : 0;
         const int b = pc / PP, r = pc % PP;
         in.off = (long)b * C * HW + (r / OWP) * W + (r % OWP);
+        if (ZERO_PAD && OWP > OW && (r % OWP) + 4 > OW) in.ok |= 2;      // this group of four ends on the padded position
         return in;
     }
     __device__ __forceinline__ f32x4 ld4(const Outer& o, const Inner& in, int& meta) const {
         bool cl;
         const f32x4 v = load4_tail_safe(x + in.off + o.off, x_end, cl);
-        meta = (int)(o.ok && in.ok) | ((int)cl << 1);
+        meta = (int)(o.ok && (in.ok & 1)) | ((int)cl << 1) | ((in.ok & 2) << 1);
         return v;
     }
     __device__ static __forceinline__ f32x4 post(const f32x4& v, int meta) {
-        return sel4(meta & 1, shift_down1(meta & 2, v));
+        f32x4 r = sel4(meta & 1, shift_down1(meta & 2, v));
+        if (ZERO_PAD) r[3] = (meta & 4) ? 0.f : r[3];
+        return r;
     }
 };
 

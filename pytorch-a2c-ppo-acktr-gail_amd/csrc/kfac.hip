@@ -51,6 +51,26 @@ static int cov_a_conv_t(const float* x, const int64_t* idx, int B, int C, float 
     return rc ? rc : launch_symmetrize_lower(out, Kc, s);
 }
 
+// stride-1 layer without a gather: both operands stream 4 padded positions per 16-byte load (zero patches at the pad)
+template <int KH, int KW, int H, int W, int OWP>
+static int cov_a_conv_pos_t(const float* x, int B, int C, float alpha, float* out, float* ws, long ws_floats,
+                            hipStream_t s) {
+    using Patch = Im2colPos<KH, KW, H, W, OWP, true, true>;
+    const int Kc = C * KH * KW, RP = B * Patch::PP;
+    Patch pop{x, x + (long)B * C * H * W, C, RP, Kc};
+    const long tt = cdiv(Kc, 128), tiles = tt * (tt + 1) / 2;
+    long max_by_ws = ws_floats / ((long)Kc * Kc) - SLAB_GROUP_EXTRA;
+    int ns = pick_slices(tiles, RP, max_by_ws < 1 ? 1 : max_by_ws);
+    if (ns > 1 && max_by_ws < ns) ns = 1;
+    RowMajorEpi e = row_major_epi(ns == 1 ? out : ws, Kc, Kc, Kc);
+    e.symmetric = 1;
+    if (ns == 1) e.scale = alpha; else e.slab_stride = (long)Kc * Kc;
+    int rc = launch_gemm<128, 128, 2, 2>(pop, pop, e, Kc, Kc, RP, ns, s);
+    if (rc) return rc;
+    if (ns > 1) rc = launch_slab_reduce(out, ws, ns, (long)Kc * Kc, (long)Kc * Kc, alpha, 0, s);
+    return rc ? rc : launch_symmetrize_lower(out, Kc, s);
+}
+
 template <int SP>
 static int cov_g_conv_t(const float* dy, int B, int OC, float alpha, float* out, float* ws, long ws_floats,
                         hipStream_t s) {
@@ -275,7 +295,10 @@ extern "C" int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_i
     const long wf = workspace ? workspace_bytes / (long)sizeof(float) : 0;
     if (H == 84 && W == 84 && KH == 8 && KW == 8 && S == 4) return cov_a_conv_t<8, 8, 4, 84, 84>(x, gather_idx, B, C, alpha, out, ws, wf, s);
     if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2) return cov_a_conv_t<4, 4, 2, 20, 20>(x, gather_idx, B, C, alpha, out, ws, wf, s);
-    if (H == 9 && W == 9 && KH == 3 && KW == 3 && S == 1) return cov_a_conv_t<3, 3, 1, 9, 9>(x, gather_idx, B, C, alpha, out, ws, wf, s);
+    if (H == 9 && W == 9 && KH == 3 && KW == 3 && S == 1) {
+        if (!gather_idx && (long)B * C * 81 < (1L << 31)) return cov_a_conv_pos_t<3, 3, 9, 9, 8>(x, B, C, alpha, out, ws, wf, s);
+        return cov_a_conv_t<3, 3, 1, 9, 9>(x, gather_idx, B, C, alpha, out, ws, wf, s);
+    }
     set_error("kfac_cov_a_conv: unsupported geometry %dx%d k%dx%d s%d", H, W, KH, KW, S);
     return -1;
 }

@@ -409,6 +409,7 @@ extern "C" int acktr_sym_eig_rocsolver_f32(float* a_inout_qt, int n, float* d, f
 namespace acktr {
 constexpr int EIG_STREAMS = 8;          // upper bound; ACKTR_EIG_STREAMS (default 8) picks how many are used:
                                         // NatureCNN's 8 large factors took 55 / 45.5 / 41.5 ms on 2 / 4 / 7 streams
+                                        // (stream priorities -- longest solve urgent, the rest low -- made it 204 ms)
 static int g_eig_nstreams = 0;
 struct EigSide { hipStream_t s; rocblas_handle h; };
 static EigSide g_side[EIG_STREAMS];

@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), 'lib', 'libacktr_hip.so')
+LIB_PATH = os.environ.get('ACKTR_HIP_LIB') or os.path.join(os.path.dirname(_HERE), 'lib', 'libacktr_hip.so')
 ABI_VERSION = 1
 
 _lib = None

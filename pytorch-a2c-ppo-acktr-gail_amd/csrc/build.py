@@ -18,6 +18,7 @@ LIB = os.path.join(LIBDIR, 'libacktr_hip.so')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-Wall', '-Wno-unused-function',
          '-I', os.path.join(ROOT, 'include'), '-I', HERE, '-I', '/opt/rocm/include']
+FLAGS += os.environ.get('ACKTR_EXTRA_FLAGS', '').split()
 LINK = ['-L/opt/rocm/lib', '-lrocsolver', '-lrocblas', '-lpthread', '-Wl,-rpath,/opt/rocm/lib']
 
 

@@ -11,6 +11,8 @@ is an addition: all T steps of a rollout in one pass, same per-step semantics as
 """
 import ctypes
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -163,6 +165,44 @@ class Discriminator(nn.Module):
         ops.gemm(ones, prod, out=gw3, trans_a=True, accumulate=True)    # d w3 += sum_b t2' * d u2
         return loss
 
+    # ------------------------------------------------------------------ one optimiser step, replayed from a hipGraph
+    def _step(self, policy_state, policy_action, expert_state, expert_action, alpha):
+        """losses + gradients + Adam for one minibatch (gail.py:67-93).  The ~45 launches of a step are latency-bound,
+        so from the third step of a given batch shape on they are replayed from a captured hipGraph whose inputs are
+        persistent buffers refilled before every replay (ACKTR_HIP_GRAPH=0 disables it)."""
+        dev = self.flat_params.device
+        if os.environ.get('ACKTR_HIP_GRAPH', '1') == '0' or ops.profiler is not None:
+            loss = self._losses_and_grads(policy_state, policy_action, expert_state, expert_action, alpha)
+            self.optimizer.step(max_grad_norm=None)                     # flat Adam; grads were just overwritten
+            return loss
+        B, Ds, Da = policy_state.shape[0], policy_state.shape[1], policy_action.shape[1]
+        key = (B, Ds, Da, self.flat_params.data_ptr())
+        st = self.__dict__.get('_gstate')
+        if st is None or st['key'] != key:
+            e = lambda *s: torch.empty(*s, dtype=f32, device=dev)
+            st = dict(key=key, seen=0, graph=None, loss=None,
+                      inp=(e(B, Ds), e(B, Da), e(B, Ds), e(B, Da), e(B, 1)))
+            self.__dict__['_gstate'] = st
+        for dst, src in zip(st['inp'], (policy_state, policy_action, expert_state, expert_action, alpha)):
+            dst.copy_(src.reshape(dst.shape), non_blocking=True)
+        if st['graph'] is None:
+            if st['seen'] < 2:                                          # warm workspaces / optimiser state launch by launch
+                st['seen'] += 1
+                loss = self._losses_and_grads(*st['inp'])
+                self.optimizer.step(max_grad_norm=None)
+                return loss
+            self.optimizer.prepare()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                st['loss'] = self._losses_and_grads(*st['inp'])
+                self.optimizer.step(max_grad_norm=None, capturing=True)
+                self.optimizer.step_count -= 1
+            st['graph'] = g
+        self.optimizer.prepare()                                        # host-side: lr / betas changes reach the device
+        st['graph'].replay()
+        self.optimizer.step_count += 1
+        return st['loss'].clone()
+
     # ------------------------------------------------------------------ reference API
     def compute_grad_pen(self, expert_state, expert_action, policy_state, policy_action, lambda_=10):
         """gail.py:29-55: the penalty value (a 0-d device tensor; no autograd graph -- use `update`)."""
@@ -184,9 +224,7 @@ class Discriminator(nn.Module):
             expert_state = torch.FloatTensor(expert_state).to(self.device)
             expert_action = expert_action.to(self.device)
             alpha = torch.rand(expert_state.size(0), 1)                 # gail.py:35 (CPU RNG stream, F7)
-            loss = self._losses_and_grads(policy_state, policy_action, expert_state, expert_action, alpha)
-            losses.append(loss)
-            self.optimizer.step(max_grad_norm=None)                     # flat Adam; grads were just overwritten
+            losses.append(self._step(policy_state, policy_action, expert_state, expert_action, alpha))
         tot = torch.stack(losses).sum(dim=1).cpu()                      # ONE host sync per update (the reference: one per batch)
         return float(tot.double().sum().item()) / len(losses)
 

@@ -131,7 +131,9 @@ class RolloutStorage(object):
     def minibatch_index_batches(self, num_mini_batch=None, mini_batch_size=None):
         """Index batches exactly as BatchSampler(SubsetRandomSampler(range(T*N)), mbs, drop_last=True)
         draws them (reference storage.py:111-125): ONE torch.randperm on the CPU default generator
-        per call (F7), trailing partial batch dropped.  Returns a list of int64 device tensors."""
+        per call (F7), trailing partial batch dropped.  Returns an iterable of int64 device tensors (slices of one
+        device copy of the permutation, cut on demand: a GAIL-style caller with mini_batch_size=128 over 2 M rows
+        consumes one or two of the 16 384 batches)."""
         num_steps, num_processes = self.rewards.size()[0:2]
         batch_size = num_processes * num_steps
         if mini_batch_size is None:
@@ -145,7 +147,7 @@ class RolloutStorage(object):
         perm = torch.randperm(batch_size)
         perm_dev = perm.to(self.rewards.device, non_blocking=True)
         nb = batch_size // mini_batch_size
-        return [perm_dev[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(nb)]
+        return (perm_dev[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(nb))
 
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
         """reference storage.py:107-143: yields the same 8-tuples, gathered on the GPU."""

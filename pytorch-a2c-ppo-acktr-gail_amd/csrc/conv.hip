@@ -176,7 +176,7 @@ int sw_num_cus() {
 // (last parameter: threads per workgroup.  3-4 waves per SIMD were measured no faster than 2 except for the conv3
 //  dgrad: the kernels are paced by the MFMA pipe and the L1, and the smaller prefetch stages that fit the tighter
 //  register budget cost more than the extra waves hide)
-using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, 8, HM_KX, 512>;
+using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, 8, HM_KX, 512, false>;
 using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, 8, HM_KY, 512>;
 using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, 12, HM_CH, 512>;
 using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 12, HM_CH, 768>;    // padded 7x7 dY, flipped 3x3 kernel

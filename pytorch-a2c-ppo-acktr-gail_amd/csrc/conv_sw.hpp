@@ -312,7 +312,10 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
     // conv2 forward, +4-8 % on conv3 and the dgrads, -3 % on conv1 whose windows barely overlap)
     const int nitems = ntiles * MG;
     const int item_stride = gridDim.x * G::NWAVES;
-    int item = G::BY_WG ? blockIdx.x * G::NWAVES + wave : blockIdx.x + gridDim.x * wave;
+    // (not BY_WG) workgroups are dispatched round-robin over the 8 XCDs: renumber them so that consecutive items run
+    // on the same XCD and share its L2 (conv1 forward: 72.5 -> 71.1 us)
+    const int bx = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
+    int item = G::BY_WG ? blockIdx.x * G::NWAVES + wave : bx + gridDim.x * wave;
     if (item >= nitems) return;
 
     VT buf[2][NL];

@@ -147,9 +147,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    // Workgroups are dispatched round-robin over the 8 XCDs (each with its own L2).  Renumber them so that workgroups
+    // that are neighbours in (x, y, z) -- same operand tiles, same K slice -- run on the SAME XCD.
+    int vx = blockIdx.x, vy = blockIdx.y, vz = blockIdx.z;
+    if constexpr (!ZBATCH) {
+        const unsigned total = gridDim.x * gridDim.y * gridDim.z;
+        if (total % 8 == 0) {
+            const unsigned L = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+            const unsigned Lp = (L % 8) * (total / 8) + L / 8;
+            vx = Lp % gridDim.x; vy = (Lp / gridDim.x) % gridDim.y; vz = Lp / (gridDim.x * gridDim.y);
+        }
+    }
+    const int n0 = vx * BN, m0 = vy * BM;
     if (EpiSym<Epi>::skip(epi, m0, n0, BN)) return;        // workgroup-uniform, before any barrier
-    const int kbeg = ZBATCH ? 0 : blockIdx.z * kchunk;     // ZBATCH: z is a phase index the functors read themselves
+    const int kbeg = ZBATCH ? 0 : vz * kchunk;     // ZBATCH: z is a phase index the functors read themselves
     int kend = kbeg + kchunk;
     if (kend > K) kend = K;
     const int nk = (kend - kbeg + GK - 1) / GK;
@@ -168,7 +179,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
     nt.init(nop, n0, tid);
 
     bool do_rowsum = false;
-    if constexpr (Epi::HAS_ROWSUM) do_rowsum = epi.wants_rowsum() && blockIdx.x == 0;     // workgroup-uniform
+    if constexpr (Epi::HAS_ROWSUM) do_rowsum = epi.wants_rowsum() && vx == 0;     // workgroup-uniform
     f32x4 rs[MT::UNITS];
 #pragma unroll
     for (int u = 0; u < MT::UNITS; ++u) rs[u] = zero4();
@@ -261,7 +272,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
                     v += __shfl_xor(v, 1);
                     v += __shfl_xor(v, 2);
                     v += __shfl_xor(v, 4);
-                    if ((tid & 7) == 0) epi.rowsum(m0 + (tid >> 3) + 32 * u, v, (int)blockIdx.z);
+                    if ((tid & 7) == 0) epi.rowsum(m0 + (tid >> 3) + 32 * u, v, vz);
                 }
             } else {                             // thread holds rows 4((tid&7)+8u)..+3 at k = tid>>3: reduce over k through LDS
                 float* red = smem;               // the main loop ended on a barrier: LDS is free
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
                     float v = 0.f;
 #pragma unroll 8
                     for (int k = 0; k < 32; ++k) v += red[k * BM + tid];
-                    epi.rowsum(m0 + tid, v, (int)blockIdx.z);
+                    epi.rowsum(m0 + tid, v, vz);
                 }
             }
         }
@@ -289,7 +300,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
         for (int a = 0; a < TM; ++a) {
             const int mb = m0 + wm * (TM * 32) + a * 32 + 4 * lh;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], (int)blockIdx.z);
+            for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], vz);
         }
     }
 }

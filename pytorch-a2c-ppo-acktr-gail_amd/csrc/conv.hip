@@ -4,6 +4,7 @@
 //   8x8 stride 4 on 84x84, 4x4 stride 2 on 20x20, 3x3 stride 1 on 9x9 (any channel counts).
 #include "conv_ops.hpp"
 #include "conv_sw.hpp"
+#include "conv_wgrad_sa.hpp"
 #include "../../include/acktr_hip.h"
 
 namespace acktr {
@@ -101,6 +102,27 @@ static int conv_wgrad_pos_t(const float* x, const float* dy, float* dw, float* d
     ConvOutPos<Patch::OH, Patch::OW, OWP> gop{dy, dy + (long)B * OC * Patch::OH * Patch::OW, OC, RP};
     Patch pop{x, x + (long)B * C * H * W, C, RP, Kc};
     return conv_wgrad_core<BM, WM, WN>(gop, pop, dw, db, OC, Kc, RP, scale, ws, ws_floats, s);
+}
+
+// 3x3 stride-1 layer with OC == 32, C == 64 and no gather: stationary accumulators (conv_wgrad_sa.hpp)
+static bool sa_wgrad_ok(int geom, int C, int OC, const int64_t* idx) { return geom == GEOM_3S1 && C == 64 && OC == SA_OC && !idx; }
+static int sa_wgrad_slabs(int B) {
+    const int cus = sw_num_cus();
+    const int per = cdiv(B, cus);                      // images per workgroup: one workgroup per CU when B allows
+    return cdiv(B, per);
+}
+static int conv3_wgrad_sa(const float* x, const float* dy, float* dw, float* db, int B, float scale, float* ws,
+                          long ws_floats, hipStream_t s) {
+    constexpr int C = 64, KC = C * SA_KK;
+    const long wk = (long)SA_OC * KC, slab = wk + SA_OC;
+    const int per = cdiv(B, sw_num_cus()), ns = cdiv(B, per);
+    if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
+    hipLaunchKernelGGL((conv3_wgrad_sa_kernel<C>), dim3(ns), dim3(C * SA_KK), 0, s, x, dy, ws, slab, B, per, scale);
+    ACKTR_LAUNCH_CHECK();
+    if (db == dw + wk) return launch_slab_reduce(dw, ws, ns, wk + SA_OC, slab, 1.f, 0, s);
+    int rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
+    if (rc || !db) return rc;
+    return launch_slab_reduce(db, ws + wk, ns, SA_OC, slab, 1.f, 0, s);
 }
 
 // dgrad weights re-packed once per call into dense per-phase matrices Wp[phase][c][k], k = (oc, a, a'), rows padded
@@ -287,7 +309,8 @@ extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, i
     const long Kc = (long)C * KH * KW;
     const int BM = OC <= 32 ? 32 : 64;
     const int OWP = (OW + 3) / 4 * 4;      // the stride-1 path reduces over padded positions
-    const int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OWP, 1024);
+    int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OWP, 1024);
+    if (sa_wgrad_ok(geom_of(H, W, KH, KW, S), C, OC, nullptr) && sa_wgrad_slabs(B) > ns) ns = sa_wgrad_slabs(B);
     return (long)(ns + SLAB_GROUP_EXTRA) * wgrad_slab_floats(OC, Kc) * (long)sizeof(float);
 }
 
@@ -308,6 +331,10 @@ extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx,
     if (geom == GEOM_4S2) return WG(4, 4, 2, 20, 20);
     if (gather_idx) return WG(3, 3, 1, 9, 9);
 #undef WG
+    if (sa_wgrad_ok(geom, C, OC, gather_idx) && (long)B * C * 81 * 4 < (1L << 31)) {   // 32-bit byte offsets
+        const int rc = conv3_wgrad_sa(x, dy, dw, db, B, in_scale, ws, wf, s);
+        if (rc != -2) return rc;
+    }
     if (OC <= 32) return conv_wgrad_pos_t<3, 3, 9, 9, 8, 32, 1, 4>(x, dy, dw, db, B, C, OC, in_scale, ws, wf, s);
     return conv_wgrad_pos_t<3, 3, 9, 9, 8, 64, 2, 2>(x, dy, dw, db, B, C, OC, in_scale, ws, wf, s);
 }

@@ -138,3 +138,23 @@ def test_gemm_all_layouts(ta, tb, M, N, K):
     assert rel(c, ref) < TOL
     c2 = ops.gemm(a.cuda(), b.cuda(), out=c.clone(), trans_a=bool(ta), trans_b=bool(tb), alpha=0.5, accumulate=True)
     assert rel(c2, 1.5 * ref) < TOL
+
+
+@pytest.mark.parametrize('B', [257, 600, 1024])
+def test_conv3_wgrad_stationary_accumulator(B):
+    """conv_wgrad_sa.hpp (3x3 stride 1, 64 -> 32 channels): several images per workgroup, ragged last workgroup, the
+    tail-safe last image; against torch fp32 on the CPU."""
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(B)
+    x = torch.relu(torch.rand(B, 64, 9, 9, generator=g) - 0.3)
+    dy = torch.randn(B, 32, 7, 7, generator=g)
+    w = torch.zeros(32, 64, 3, 3, requires_grad=True)
+    bias = torch.zeros(32, requires_grad=True)
+    torch.nn.functional.conv2d(x, w, bias).backward(dy)
+    flat = torch.full((32 * 576 + 32,), 3.0, device='cuda')          # dw and db adjacent, like the flat gradient buffer
+    dw, db = flat[:32 * 576].view(32, 64, 3, 3), flat[32 * 576:]
+    ops.conv2d_wgrad(x.cuda(), dy.cuda(), (32, 64, 3, 3), 1, dw, db)
+    assert rel(dw, w.grad) < 2e-5 and rel(db, bias.grad) < 2e-5
+    dw2 = torch.empty(32, 64, 3, 3, device='cuda')                   # separate buffers, no bias
+    ops.conv2d_wgrad(x.cuda(), dy.cuda(), (32, 64, 3, 3), 1, dw2, None)
+    assert torch.equal(dw2, dw)

@@ -152,6 +152,18 @@ typedef struct acktr_loss_args {
 long acktr_policy_loss_workspace_bytes(int B, int A);
 int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream);
 
+/* The NatureCNN + Categorical step between the FC features and their gradient in one launch (+ a fixed-order finalize):
+ * head = feat Wh^T + bh with Wh = [critic_linear.weight; dist.linear.weight] ([1+A, H], adjacent in the flat buffer)
+ * -- model.py:185,195, distributions.py:69-73; then the loss of acktr_policy_loss_f32 (same args; `values` / `dvalues`
+ * are OUTPUTS here: the [B, ld] head and d(loss)/d(head) rows, column 0 the value, 1..A the logits; `dist_in`, `ddist`
+ * are ignored); dfeat[B,H] = (dhead Wh) * (feat > 0) (the FC layer's ReLU, model.py:180); dwh[1+A,H] = dhead^T feat,
+ * dbh[1+A] = column sums of dhead (autograd of the two nn.Linear).  H == 512, 1+A <= 8, dist 0 only
+ * (acktr_head_step_supported); args->workspace >= acktr_head_step_workspace_bytes(B, H, A), 16-byte aligned. */
+int acktr_head_step_supported(int B, int H, int A, int dist);
+long acktr_head_step_workspace_bytes(int B, int H, int A);
+int acktr_head_step_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh, float* dfeat,
+                        float* dwh, float* dbh, int H, void* stream);
+
 /* dist.log_probs(action) and dist.entropy() per sample -- model.py:74-77 (entropy.mean() is taken by the host). */
 int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions, int B, int A,
                        float* logp, float* entropy, void* stream);

@@ -167,12 +167,16 @@ class A2C_ACKTR():
                                       returns=returns, value_coef=self.value_loss_coef,
                                       entropy_coef=self.entropy_coef)
             else:
-                acts = engine.forward(ac, obs_flat, gather_idx=idx, rnn_hxs=hxs, masks=masks)   # a2c_acktr.py:38-43
+                # A2C on the NatureCNN: head, loss and the head's backward in one launch (ACKTR keeps the layer-wise
+                # path: its statistics pass reads the head activations)
+                fuse_head = not self.acktr and hxs is None and engine.head_step_ok(ac, nloc)
+                acts = engine.forward(ac, obs_flat, gather_idx=idx, rnn_hxs=hxs, masks=masks,
+                                      head=not fuse_head)                                    # a2c_acktr.py:38-43
                 if self.acktr and self.optimizer.steps % self.optimizer.Ts == 0:
                     self.optimizer.accumulate_stats(acts, actions, idx, inv_batch, self.dp)  # a2c_acktr.py:53-68
-                engine.policy_loss(ac, acts, engine.ALGO_A2C, actions, loss_acc, inv_batch, returns=returns,
-                                   gather_idx=idx, value_coef=self.value_loss_coef,
-                                   entropy_coef=self.entropy_coef)                          # a2c_acktr.py:48-51,70-72
+                (engine.head_step if fuse_head else engine.policy_loss)(
+                    ac, acts, engine.ALGO_A2C, actions, loss_acc, inv_batch, returns=returns, gather_idx=idx,
+                    value_coef=self.value_loss_coef, entropy_coef=self.entropy_coef)        # a2c_acktr.py:48-51,70-72
                 engine.backward(ac, acts, ac.flat_grads)
             self.dp.all_reduce_sum_(ac.flat_grads)
             if self.acktr == False:

@@ -117,11 +117,14 @@ class PPO():
                                   value_coef=self.value_loss_coef, entropy_coef=self.entropy_coef,
                                   use_clipped_value_loss=self.use_clipped_value_loss)
             return
-        acts = engine.forward(ac, b['obs'], gather_idx=b['idx'], rnn_hxs=b.get('hxs'), masks=b.get('masks'))
-        engine.policy_loss(ac, acts, engine.ALGO_PPO, b['actions'], b['loss_acc'], b['inv_batch'],
-                           old_logp=b['old_logp'], old_values=b['old_values'], returns=b['returns'], adv=b['adv'],
-                           gather_idx=b['idx'], clip=self.clip_param, value_coef=self.value_loss_coef,
-                           entropy_coef=self.entropy_coef, use_clipped_value_loss=self.use_clipped_value_loss)
+        fuse_head = b.get('hxs') is None and engine.head_step_ok(ac, nrows)
+        acts = engine.forward(ac, b['obs'], gather_idx=b['idx'], rnn_hxs=b.get('hxs'), masks=b.get('masks'),
+                              head=not fuse_head)
+        (engine.head_step if fuse_head else engine.policy_loss)(
+            ac, acts, engine.ALGO_PPO, b['actions'], b['loss_acc'], b['inv_batch'],
+            old_logp=b['old_logp'], old_values=b['old_values'], returns=b['returns'], adv=b['adv'],
+            gather_idx=b['idx'], clip=self.clip_param, value_coef=self.value_loss_coef,
+            entropy_coef=self.entropy_coef, use_clipped_value_loss=self.use_clipped_value_loss)
         engine.backward(ac, acts, ac.flat_grads, phase=phase)
         self._acts = acts if phase == 1 else None
 

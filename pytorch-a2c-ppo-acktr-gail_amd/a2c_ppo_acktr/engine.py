@@ -176,7 +176,8 @@ def gru_backward(policy, a, dout, gflat, wgrad=True, dx_gate_src=None, dx_gate=N
     return None
 
 
-def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None):
+def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True):
+    """head=False stops at the FC features (`head_step` then runs head, loss and their backward in one launch)."""
     inputs = inputs.contiguous()
     _check_input(policy, inputs, gather_idx)
     rec = policy.is_recurrent
@@ -199,8 +200,9 @@ def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None):
         a.flat3 = a.y3.view(a.y3.shape[0], -1)
         a.feat = ops.linear_fwd(a.flat3, L['fc'][0], L['fc'][1].view(-1), 'relu')
         a.head_in = gru_forward(policy, a, a.feat, rnn_hxs, masks) if rec else a.feat
-        wh, bh = head_views(policy, policy.flat_params)
-        a.head = ops.linear_fwd(a.head_in, wh, bh, None)
+        if head:
+            wh, bh = head_views(policy, policy.flat_params)
+            a.head = ops.linear_fwd(a.head_in, wh, bh, None)
         return a
     L = mlp_layer_params(policy)
     a = Acts(False)
@@ -269,10 +271,13 @@ def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None):
         wh, _ = head_views(policy, policy.flat_params)
         w3, w2, w1 = L['conv3'][0], L['conv2'][0], L['conv1'][0]
         if phase != 2:
-            if wgrad:
+            fused = getattr(acts, 'dfeat_fused', None)          # head_step already produced dWh, dbh and dfeat
+            if wgrad and fused is None:
                 gwh, gbh = head_views(policy, gflat)
                 ops.linear_wgrad(acts.dhead, acts.head_in, gwh, gbh)
-            if policy.is_recurrent:
+            if fused is not None:
+                dfeat = fused
+            elif policy.is_recurrent:
                 dgru = ops.linear_dgrad(acts.dhead, wh)
                 dfeat = gru_backward(policy, acts, dgru, gflat, wgrad=wgrad, dx_gate_src=acts.feat, dx_gate='relu')
             else:
@@ -360,6 +365,58 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
     args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     rc = L.acktr_policy_loss_f32(ctypes.byref(args), _hip.cur_stream(dev))
     _hip.check(rc, 'acktr_policy_loss_f32')
+
+
+# ----------------------------------------------------------------------------------------------
+# fused head + loss + head backward of the NatureCNN / Categorical path (csrc/head_fused.hip)
+# ----------------------------------------------------------------------------------------------
+FUSED_HEAD = os.environ.get('ACKTR_FUSED_HEAD', '1') != '0'
+
+
+def head_step_ok(policy, B):
+    """Non-recurrent CNNBase(hidden 512) + Categorical with at most 7 actions; anything else runs layer by layer."""
+    if not FUSED_HEAD or not is_cnn(policy) or policy.is_recurrent:
+        return False
+    hidden = cnn_layer_params(policy)['critic'][0].shape[1]
+    return bool(_hip.lib().acktr_head_step_supported(int(B), int(hidden), int(policy.dist.num_outputs),
+                                                     int(policy.dist.kind)))
+
+
+def head_step(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, old_values=None, returns=None, adv=None,
+              gather_idx=None, clip=0.0, value_coef=0.0, entropy_coef=0.0, use_clipped_value_loss=True, gflat=None,
+              logp_out=None):
+    """After forward(..., head=False): fills acts.head / acts.dhead / acts.dfeat_fused, writes the head's weight and
+    bias gradients into `gflat` and adds this batch's (value_loss, action_loss, entropy) to loss_acc."""
+    feat = acts.head_in
+    dev = feat.device
+    B, H = feat.shape
+    A = policy.dist.num_outputs
+    L = _hip.lib()
+    gflat = policy.flat_grads if gflat is None else gflat
+    wh, bh = head_views(policy, policy.flat_params)
+    gwh, gbh = head_views(policy, gflat)
+    acts.head = torch.empty(B, 1 + A, dtype=f32, device=dev)
+    acts.dhead = torch.empty(B, 1 + A, dtype=f32, device=dev)
+    dfeat = torch.empty(B, H, dtype=f32, device=dev)
+    args = _hip.LossArgs()
+    args.algo, args.dist, args.B, args.A = algo, 0, B, A
+    p = lambda t, dt=f32, name='head step operand': (None if t is None else _hip.dev_ptr(t, dt, name).value)
+    args.values, args.ld_values = p(acts.head), 1 + A
+    args.dvalues, args.ld_dvalues = p(acts.dhead), 1 + A
+    args.actions = p(actions, torch.int64, 'actions')
+    args.old_logp, args.old_values, args.returns, args.adv = p(old_logp), p(old_values), p(returns), p(adv)
+    args.gather_idx = p(gather_idx, torch.int64, 'gather_idx')
+    args.clip, args.value_coef, args.entropy_coef, args.inv_batch = clip, value_coef, entropy_coef, inv_batch
+    args.use_clipped_value_loss = 1 if use_clipped_value_loss else 0
+    args.logp_out = p(logp_out)
+    args.loss_acc = p(loss_acc)
+    ws = ops.workspace(dev, L.acktr_head_step_workspace_bytes(B, H, A), 'head')
+    args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    with ops._Timed('head%dx%d_step' % (H, 1 + A), 6.0 * B * H * (1 + A)):
+        rc = L.acktr_head_step_f32(ctypes.byref(args), p(feat), p(wh.detach()), p(bh.detach()), p(dfeat), p(gwh), p(gbh),
+                                   H, _hip.cur_stream(dev))
+    _hip.check(rc, 'acktr_head_step_f32')
+    acts.dfeat_fused = dfeat
 
 
 # ----------------------------------------------------------------------------------------------

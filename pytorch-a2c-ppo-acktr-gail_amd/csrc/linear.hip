@@ -45,6 +45,44 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(float* dst, const flo
     }
 }
 
+// Many slabs, few columns (the conv weight gradients: hundreds of slabs of 8-32 K floats): ONE pass in which sixteen
+// lanes share a float4 column -- lane group `sub` sums slabs sub, sub+16, ... (all loads independent, so a lane has its
+// whole share in flight at once) and a four-step butterfly adds the sixteen partials.  The order is fixed, so the
+// result is run-to-run deterministic like the two-pass form it replaces (two launches of ~5 us each, both
+// latency-bound).  Four adjacent columns per wave keep each request 64 contiguous bytes.
+__global__ __launch_bounds__(256) void slab_reduce_wave_kernel(float* __restrict__ dst, const float* __restrict__ slabs,
+                                                               int nslabs, long n4, long stride, float scale,
+                                                               int accumulate, const float* __restrict__ bias, int ncols,
+                                                               int act) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = ((long)blockIdx.x * 4 + wave) * 4 + (lane & 3);
+    const int sub = lane >> 2;
+    f32x4 acc = zero4();
+    if (i < n4) {
+#pragma unroll 8
+        for (int k = sub; k < nslabs; k += 16) acc = acc + *reinterpret_cast<const f32x4*>(slabs + (long)k * stride + 4 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = acc[j];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[j] = v;
+    }
+    if (sub != 0 || i >= n4) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = acc[j] * scale;
+        if (bias) v += bias[(4 * i + j) % ncols];
+        if (act == 1) v = v > 0.f ? v : 0.f;
+        else if (act == 2) v = tanhf(v);
+        if (accumulate) v += dst[4 * i + j];
+        dst[4 * i + j] = v;
+    }
+}
+
 int launch_slab_reduce_ex(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,
                           const float* bias, int ncols, int act, float* group_ws, hipStream_t stream) {
     if (n <= 0) return 0;
@@ -55,6 +93,12 @@ int launch_slab_reduce_ex(float* dst, const float* slabs, int nslabs, long n, lo
     const long n4 = n / 4;
     int bx = cdiv(n4, 256);
     if (bx > 1024) bx = 1024;
+    if (nslabs >= 16 && n4 <= 16384) {
+        hipLaunchKernelGGL(slab_reduce_wave_kernel, dim3(cdiv(n4, 16)), dim3(256), 0, stream, dst, slabs, nslabs, n4, stride,
+                           scale, accumulate, bias, ncols, act);
+        ACKTR_LAUNCH_CHECK();
+        return 0;
+    }
     const int groups = (group_ws && nslabs >= 16) ? (nslabs >= 128 ? 32 : 8) : 1;
     if (groups == 1) {
         hipLaunchKernelGGL(slab_reduce4_kernel, dim3(bx, 1), dim3(256), 0, stream, dst, slabs, 0, nslabs, n4, stride, scale,

@@ -237,3 +237,78 @@ def test_mlp_fused_step_matches_layer_path(od, A, B, algo_id):
         a_, b_ = pol.grad_view(p, g_fused).cpu().numpy().reshape(-1), pol.grad_view(p, g_ref).cpu().numpy().reshape(-1)
         err = np.linalg.norm(a_ - b_) / max(np.linalg.norm(b_), 1e-20)
         assert err < 2e-5, '%s rel err %g' % (n, err)
+
+
+@pytest.mark.parametrize('ci', [i for i, c in enumerate(EVAL_CASES) if c[1] == 'cnn'])
+def test_fused_head_step_path(ci):
+    """engine.forward(head=False) -> head_step (head + loss + head backward in one launch) -> engine.backward:
+    what PPO.update runs on the NatureCNN / Categorical path; against the reference goldens."""
+    from a2c_ppo_acktr import engine
+    tag, kind, od, A, B, clip, c_e = EVAL_CASES[ci]
+    G = golden('eval')
+    pol = make_policy(kind, od, A, 40 + ci)
+    assert engine.head_step_ok(pol, B)
+    x_np = eval_case_inputs(tag, kind, od, A, B, ci)
+    x = {k: t(v).cuda() for k, v in x_np.items()}
+    olp = t(G[tag + '/old_logp']).cuda().view(-1)
+    loss_acc = torch.zeros(3, device='cuda')
+    logp = torch.empty(B, device='cuda')
+    with torch.no_grad():
+        acts = engine.forward(pol, x['obs'], head=False)
+        engine.head_step(pol, acts, engine.ALGO_PPO, x['act'].view(-1).contiguous(), loss_acc, 1.0 / B, old_logp=olp,
+                         old_values=x['vp'].view(-1), returns=x['ret'].view(-1), adv=x['adv'].view(-1), clip=clip,
+                         value_coef=0.5, entropy_coef=c_e, logp_out=logp)
+        engine.backward(pol, acts, pol.flat_grads)
+    vl, al, en = loss_acc.tolist()
+    assert close(vl, float(G[tag + '/value_loss']))
+    assert close(al, float(G[tag + '/action_loss']))
+    assert close(en, float(G[tag + '/entropy']))
+    np.testing.assert_allclose(acts.head[:, 0:1].cpu().numpy(), G[tag + '/values'], rtol=TOL, atol=2e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), G[tag + '/logp'].reshape(-1), rtol=TOL, atol=2e-5)
+    grads = OrderedDict((n, pol.grad_view(p).cpu().numpy()) for n, p in pol.named_parameters())
+    check_grads(G, tag, kind, od, A, 40 + ci, pol, x_np, grads, clip, c_e)
+
+
+@pytest.mark.parametrize('B,A,algo_id,gather', [(1024, 6, 0, True), (37, 6, 0, False), (1, 2, 1, False), (2500, 7, 2, True),
+                                                (80, 4, 1, True), (640, 6, 2, False)])
+def test_head_step_matches_layer_path(B, A, algo_id, gather):
+    """acktr_head_step_f32 against the layer-by-layer operators it replaces (skinny forward, loss kernel, skinny
+    dgrad / wgrad) on random features: ragged row counts, more rows than one pass of the grid, all three losses."""
+    from a2c_ppo_acktr import engine, ops
+    from a2c_ppo_acktr.model import Policy
+    torch.manual_seed(B + A)
+    pol = Policy((4, 84, 84), Discrete(A))
+    pol.to('cuda')
+    g = torch.Generator(device='cuda').manual_seed(3 * B + algo_id)
+    R = B + 11 if gather else B                         # rollout-side arrays are longer than the minibatch
+    feat = torch.randn(B, 512, device='cuda', generator=g).clamp_(min=0)       # post-ReLU features, many exact zeros
+    idx = torch.randperm(R, device='cuda', generator=g)[:B].contiguous() if gather else None
+    actions = torch.randint(0, A, (R,), device='cuda', generator=g)
+    old_logp = 0.1 * torch.randn(R, device='cuda', generator=g) - 1.5
+    old_v, ret, adv = (torch.randn(R, device='cuda', generator=g) for _ in range(3))
+    kw = dict(old_logp=old_logp, old_values=old_v, returns=ret, adv=adv, gather_idx=idx, clip=0.1, value_coef=0.5,
+              entropy_coef=0.01)
+    out = []
+    for fused in (False, True):
+        acts = engine.Acts(True)
+        acts.feat = acts.head_in = feat
+        gflat = torch.zeros_like(pol.flat_params)
+        loss_acc = torch.zeros(3, device='cuda')
+        logp = torch.empty(B, device='cuda')
+        with torch.no_grad():
+            if fused:
+                engine.head_step(pol, acts, algo_id, actions, loss_acc, 1.0 / B, gflat=gflat, logp_out=logp, **kw)
+                dfeat = acts.dfeat_fused
+            else:
+                wh, bh = engine.head_views(pol, pol.flat_params)
+                acts.head = ops.linear_fwd(feat, wh, bh, None)
+                engine.policy_loss(pol, acts, algo_id, actions, loss_acc, 1.0 / B, gflat=gflat, logp_out=logp, **kw)
+                gwh, gbh = engine.head_views(pol, gflat)
+                ops.linear_wgrad(acts.dhead, feat, gwh, gbh)
+                dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=feat, gate='relu')
+        gwh, gbh = engine.head_views(pol, gflat)
+        out.append([v.cpu().numpy().astype(np.float64) for v in (acts.head, acts.dhead, dfeat, gwh, gbh, loss_acc, logp)])
+    for name, a, b in zip(('head', 'dhead', 'dfeat', 'dwh', 'dbh', 'losses', 'logp'), out[1], out[0]):
+        err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        assert err < 2e-5, '%s: fused vs layer path rel err %g' % (name, err)
+    assert np.array_equal(out[1][2] == 0, out[0][2] == 0) or (out[1][2] != 0).sum() > 0

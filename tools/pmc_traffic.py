@@ -9,7 +9,7 @@ import csv, json, sys
 OPS = [('conv8s4_fwd', 'SwGeom<8, 8, 4, 84, 84, 4,'), ('conv4s2_fwd', 'SwGeom<4, 4, 2, 20, 20, 32,'),
        ('conv3s1_fwd', 'SwGeom<3, 3, 1, 9, 9, 64,'), ('conv3s1_dgrad', 'SwGeom<3, 3, 1, 11, 11, 32,'),
        ('conv4s2_dgrad', 'SwGeom<2, 2, 1, 11, 11, 64,'), ('conv8s4_wgrad', 'ConvOutKC<400>'),
-       ('conv4s2_wgrad', 'ConvOutKC<81>'), ('conv3s1_wgrad', 'ConvOutPos<7, 7, 8>'),
+       ('conv4s2_wgrad', 'ConvOutKC<81>'), ('conv3s1_wgrad', 'conv3_wgrad_sa_kernel'),
        ('linear1568x512_fwd', 'DenseKCT<true>, acktr::DenseKCT<true>'),
        ('linear1568x512_wgrad', 'DenseRCT<true>, acktr::DenseRCT<true>'),
        ('linear1568x512_dgrad', 'DenseKCT<true>, acktr::DenseRCT<true>')]
@@ -17,7 +17,7 @@ f = {r['kernel']: r for r in csv.DictReader(open(sys.argv[1]))}
 w = {r['kernel']: r for r in csv.DictReader(open(sys.argv[2]))}
 out = {}
 for op, pat in OPS:
-    ks = [k for k in f if pat in k and ('conv_sw_kernel' in k or 'gemm_mfma' in k)]
+    ks = [k for k in f if pat in k and ('conv_sw_kernel' in k or 'gemm_mfma' in k or 'wgrad_sa_kernel' in k)]
     if len(ks) != 1:
         continue
     k = ks[0]

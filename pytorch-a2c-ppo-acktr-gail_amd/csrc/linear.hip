@@ -1,6 +1,7 @@
 // Linear layers (forward / dgrad / wgrad / bias grad) on the fp32 MFMA tile GEMM, plus the shared
 // fixed-order slab reduction.  Replaces the torch.nn.Linear call sites of the reference policy:
 // model.py:180,185,208-216 and distributions.py:69,83 (forward) and their autograd backward.
+#include <stdlib.h>
 #include "gemm_core.hpp"
 #include "../../include/acktr_hip.h"
 
@@ -151,9 +152,14 @@ int launch_slab_reduce(float* dst, const float* slabs, int nslabs, long n, long 
 // otherwise 64x64 (37 KB, 4/CU) -- the 1024x512x1568-class layers of this workload ran at < 1 wave per SIMD on
 // 64x128.  Skinny shapes get 128x32 / 32x128.  Split-K supplies the rest (see pick_slices).
 enum { TILE_128x32, TILE_32x128, TILE_64x64, TILE_64x128, TILE_128x128 };
+static int env_int(const char* name) {           // tuning overrides for tools/opbench.py sweeps (unset in production)
+    const char* v = getenv(name);
+    return v ? atoi(v) : 0;
+}
 static int tile_cfg(int M, int N) {
     if (N <= 64) return TILE_128x32;
     if (M <= 32) return TILE_32x128;
+    if (const int t = env_int("ACKTR_TILE")) return t;
     if ((long)cdiv(M, 128) * cdiv(N, 128) >= 192) return TILE_128x128;
     if ((long)cdiv(M, 64) * cdiv(N, 128) >= 256) return TILE_64x128;
     return TILE_64x64;
@@ -230,9 +236,12 @@ int launch_symmetrize_lower(float* c, int n, hipStream_t stream) {
 
 int pick_slices(long tiles, long K, long max_by_ws) {
     long want = 768 / (tiles > 0 ? tiles : 1);
+    if (tiles >= 160 && K <= 2048) want = 1;   // the tiles alone nearly fill the chip and K is short: a split would only
+                                               // add slab traffic and a reduction launch (FC wgrad, 200 tiles: 36.2 vs 39.5 us)
     long by_k = K / (4 * GK);              // at least 4 K tiles per slice
     long n = want;
     if (n > by_k) n = by_k;
+    if (const int f = env_int("ACKTR_WGRAD_SLICES")) n = f;
     if (n > max_by_ws) n = max_by_ws;
     if (n > 1024) n = 1024;
     if (n < 1) n = 1;
@@ -247,8 +256,10 @@ static int fwd_slices(int B, int IN, int OUT, long ws_floats) {
     if (((long)B * OUT) % 4) return 1;
     long max_by_ws = ws_floats / ((long)B * OUT) - SLAB_GROUP_EXTRA;
     long want = 768 / gemm_tiles(B, OUT);
-    long by_k = IN / (8 * GK);                 // at least 8 K tiles per slice
+    long by_k = IN / (12 * GK);                // at least 12 K tiles per slice (FC 1568 -> 512 at B = 1024: 4 slices 31.9 us,
+                                               // 6 slices 34.6, 8 slices 36.9 -- the slabs cost more than the extra waves buy)
     long n = want < by_k ? want : by_k;
+    if (const int f = env_int("ACKTR_FWD_SLICES")) n = f;
     if (n > max_by_ws) n = max_by_ws;
     if (n > 16) n = 16;
     return n < 2 ? 1 : (int)n;

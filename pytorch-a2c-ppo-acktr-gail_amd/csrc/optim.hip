@@ -62,6 +62,18 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
     __shared__ float sm2[2];
     __shared__ float sm_adam[2];
     float coef = 1.0f;
+    // The first (for this workload: only) float4 group of the thread is requested BEFORE the serial preamble below
+    // (two double pow()s on one lane, the fixed-order sum of the norm partials, two barriers), which otherwise sits
+    // in front of every load of the kernel.
+    typedef float v4 __attribute__((ext_vector_type(4)));
+    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) == 0);
+    const long n4 = vec ? n / 4 : 0;
+    const long i_first = (long)blockIdx.x * OPT_THREADS + threadIdx.x;
+    v4 pv0 = {0.f, 0.f, 0.f, 0.f}, gv0 = pv0, av0 = pv0, bv0 = pv0;
+    if (i_first < n4) {
+        pv0 = reinterpret_cast<v4*>(p)[i_first]; gv0 = reinterpret_cast<v4*>(g)[i_first]; av0 = reinterpret_cast<v4*>(s1)[i_first];
+        if (MODE == 0) bv0 = reinterpret_cast<v4*>(s2)[i_first];
+    }
     if (hyper_dev) {
         const float lr = hyper_dev[0];
         eps = hyper_dev[3];
@@ -98,13 +110,13 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
             pi = pi - lr_or_step * (gi / avg);                       // addcdiv_(grad, avg, -lr)
         }
     };
-    typedef float v4 __attribute__((ext_vector_type(4)));
-    const bool vec = ((((uintptr_t)p | (uintptr_t)g | (uintptr_t)s1 | (uintptr_t)s2) & 15) == 0);
-    const long n4 = vec ? n / 4 : 0;
-    for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n4; i += (long)gridDim.x * OPT_THREADS) {
-        v4 pv = reinterpret_cast<v4*>(p)[i], gv = reinterpret_cast<v4*>(g)[i], av = reinterpret_cast<v4*>(s1)[i];
-        v4 bv = av;
-        if (MODE == 0) bv = reinterpret_cast<v4*>(s2)[i];
+    for (long i = i_first; i < n4; i += (long)gridDim.x * OPT_THREADS) {
+        v4 pv = pv0, gv = gv0, av = av0, bv = MODE == 0 ? bv0 : av0;
+        if (i != i_first) {
+            pv = reinterpret_cast<v4*>(p)[i]; gv = reinterpret_cast<v4*>(g)[i]; av = reinterpret_cast<v4*>(s1)[i];
+            bv = av;
+            if (MODE == 0) bv = reinterpret_cast<v4*>(s2)[i];
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) { float pj = pv[j], gj = gv[j], aj = av[j], bj = bv[j]; upd(pj, gj, aj, bj); pv[j] = pj; gv[j] = gj; av[j] = aj; bv[j] = bj; }
         reinterpret_cast<v4*>(p)[i] = pv;

@@ -25,13 +25,23 @@ constexpr int HS_ROWS = HS_RPW * HS_WAVES;
 constexpr int HS_TAIL = 12;        // per-slab tail: 8 bias sums, value loss, action loss, entropy, pad
 constexpr int HS_MAX_SLABS = 128;
 
-__device__ __forceinline__ float wave_allsum(float v) {      // butterfly: the same bits in every lane
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
 __device__ __forceinline__ float lane_bcast(float v, int l) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+// Sum over the 64 lanes, the same bits in every lane: four DPP steps inside each 16-lane row (quad_perm [1,0,3,2],
+// [2,3,0,1], row_half_mirror, row_mirror -- every step adds two partials that both partners hold, and the addition
+// commutes), then the four row sums in row order through readlane.  (__shfl_xor is a ds_bpermute round trip per
+// step: 6 dependent LDS round trips per sum were most of this kernel's time.)
+__device__ __forceinline__ float wave_allsum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    return ((lane_bcast(v, 0) + lane_bcast(v, 16)) + lane_bcast(v, 32)) + lane_bcast(v, 48);
 }
 __device__ __forceinline__ float dot4(const hf4& a, const hf4& b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
@@ -87,7 +97,7 @@ __global__ __launch_bounds__(256) void head_step_kernel(acktr_loss_args a, const
             for (int o = 0; o < HS_OUT; ++o) p[o] = dot4(x[r][0], w[o][0]) + dot4(x[r][1], w[o][1]);
 #pragma unroll
             for (int o = 0; o < HS_OUT; ++o) {
-                p[o] = o < OUT ? wave_allsum(p[o]) + bias[o] : 0.f;
+                p[o] = wave_allsum(p[o]) + bias[o];          // rows o >= OUT have zero weights and bias: no branch
                 hp[o] = (lane & (HS_RPW - 1)) == r ? p[o] : hp[o];
             }
         }

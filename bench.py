@@ -176,6 +176,24 @@ def side_metrics(device):
                                samples_per_s=round(T * N * len(ms) / (sum(ms) * 1e-3), 1),
                                kfac_step_ms=dict(with_eig=round(statistics.median(eig), 3) if eig else None,
                                                  without_eig=round(statistics.median(plain), 3), n_eig=len(eig)))
+    # ---- configs[2] at the top of its range on ONE GPU: 256 processes x 128 steps, 4 epochs x 4 minibatches of 8192
+    # (the headline line keeps 32 processes per GPU so that 8 GPUs land on this global size)
+    T, N = T_STEPS, 256
+    ro = synth_rollouts(T, N, device, seed=27)
+    pol, agent = build_agent(device, seed=7)
+    rs = fill_storage(ro, device)
+    rs.compute_returns(ro['next_value'], True, 0.99, 0.95, True)
+    _timed_updates(agent, rs, 2, 800)
+    ms = _timed_updates(agent, rs, 5, 810)
+    med = statistics.median(ms)
+    spu = T * N * PPO_HP['ppo_epoch']
+    out['ppo_update_256procs'] = dict(workload='PPO.update NatureCNN, 256 procs x 128 steps on one GPU (minibatch 8192)',
+                                      ms_median=round(med, 3), samples_per_s=round(spu / (med * 1e-3), 1),
+                                      mfma_tflops=round(spu * FWD_BWD_FLOP_PER_SAMPLE / (med * 1e-3) / 1e12, 2),
+                                      frac_of_f32_mfma_peak=round(spu * FWD_BWD_FLOP_PER_SAMPLE / (med * 1e-3) / 1e12
+                                                                  / MFMA_F32_PEAK_TFLOPS, 4))
+    del rs, agent, pol, ro
+    torch.cuda.empty_cache()
     # ---- GAE scan (20 B per element: GAE + proper time limits): the stress size of configs[4], where the serial
     # chain of 2048 steps on only 1024 lanes is the floor, and a wide rollout where HBM is
     for T, N in ((2048, 1024), (512, 65536)):

@@ -84,6 +84,18 @@ long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, int OC, int 
 int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
                            int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, int prepacked,
                            void* stream);
+/* The same with the zero-padding passes between chained dgrads folded into the producers (launch scheduling and data
+ * layout only; no counterpart in the reference):
+ *   flags bit 0 = prepacked (as above); bit 1 = the zero-padded dY ALREADY sits in `workspace` at
+ *   acktr_conv2d_dgrad_padded_dy_offset_bytes(...) ([B, OC, 11, 11] planes for the two stationary geometries: 7x7 dY
+ *   padded by 2, 9x9 dY padded by 1), written there by the producer of dY; `dy` may then be NULL and the padding launch
+ *   is skipped.  The caller keeps the borders of that region zero (allocate it zeroed; producers write interiors only).
+ *   dx_padded (nullable; 3x3 stride-1 stationary path only): dx is ALSO written as [B, C, H+2*pad, W+2*pad] planes,
+ *   interior only -- point it at the next layer's padded-dY region. */
+long acktr_conv2d_dgrad_padded_dy_offset_bytes(int C, int H, int W, int OC, int KH, int KW, int S);
+int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
+                              int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, int flags,
+                              float* dx_padded, int pad, void* stream);
 
 /* Re-ordered weights of up to 8 conv layers in ONE launch (no counterpart call in the reference: it is the weight
  * preparation the forward / dgrad entry points above otherwise launch themselves, model.py:176-179).  Each job names a
@@ -105,6 +117,11 @@ int acktr_linear_fwd_f32(const float* x, const float* w, const float* bias, floa
  * gate_src[B,IN] = the activation that feeds this layer. */
 int acktr_linear_dgrad_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx, int B, int IN,
                            int OUT, int accumulate, void* stream);
+/* The same, also writing dx as zero-padded planes: row b of dx read as [C, OH, OW] (IN == C*OH*OW) goes to
+ * dx_padded[b, c, y+pad, x+pad] of [B, C, OH+2*pad, OW+2*pad] (interior only; the caller keeps the borders zero) --
+ * the dY layout of the conv dgrad behind an FC layer (see acktr_conv2d_dgrad_ex_f32).  dx_padded nullable. */
+int acktr_linear_dgrad_ex_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx, int B, int IN,
+                              int OUT, int accumulate, float* dx_padded, int C, int OH, int OW, int pad, void* stream);
 /* dw[OUT,IN] = dy^T x ; db[OUT] = column sums of dy (db nullable). */
 long acktr_linear_wgrad_workspace_bytes(int B, int IN, int OUT);
 int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT,

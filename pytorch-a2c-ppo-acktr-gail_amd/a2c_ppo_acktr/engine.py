@@ -284,7 +284,14 @@ def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None):
                 dfeat = ops.linear_dgrad(acts.dhead, wh, gate_src=acts.feat, gate='relu')
             if wgrad:
                 ops.linear_wgrad(dfeat, acts.flat3, gv(L['fc'][0]), gv(L['fc'][1]).view(-1))
-            dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu').view_as(acts.y3)
+            # the zero-padded copies of dy3 / dy2 that the stationary dgrads read are written by the PRODUCERS of dy3 /
+            # dy2 (FC dgrad epilogue, conv3 dgrad epilogue) straight into those layers' workspaces: two padding
+            # passes (8.5 + 12.8 us of a 655 us step at B = 1024) disappear
+            B3 = acts.y3.shape[0]
+            acts.pd3 = ops.padded_dy_view(acts.packs.get('d3'), B3, w3, 1, 9) if FOLD_PAD else None
+            acts.pd2 = ops.padded_dy_view(acts.packs.get('d2'), B3, w2, 2, 20) if FOLD_PAD else None
+            dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu', padded_out=acts.pd3,
+                                   planes=tuple(acts.y3.shape[1:])).view_as(acts.y3)
             if wgrad:
                 ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
             if phase == 1:
@@ -292,10 +299,13 @@ def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None):
                 return
         else:
             dfeat, dy3 = acts.dfeat, acts.dy3
-        dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1, packed=acts.packs.get('d3'))
+        pd3 = acts.pd3
+        pd2 = acts.pd2 if pd3 is not None else None           # (conv3 dgrad off the stationary path: nobody fills pd2)
+        dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1, packed=acts.packs.get('d3'), dy_prepadded=pd3 is not None,
+                               padded_out=pd2)
         if wgrad:
             ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1))
-        dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2, packed=acts.packs.get('d2'))
+        dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2, packed=acts.packs.get('d2'), dy_prepadded=pd2 is not None)
         if wgrad:
             ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1),
                              in_scale=1.0 / 255.0, gather_idx=acts.idx)
@@ -423,6 +433,7 @@ def head_step(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, o
 # one-launch MLP minibatch step (csrc/mlp_fused.hip)
 # ----------------------------------------------------------------------------------------------
 FUSED_MLP = os.environ.get('ACKTR_FUSED_MLP', '1') != '0'
+FOLD_PAD = os.environ.get('ACKTR_FOLD_PAD', '1') != '0'
 
 
 def mlp_fused_ok(policy, B):

@@ -86,7 +86,9 @@ def pack_conv_weights(layers, B, cache):
             continue
         ws = cache.get(key)
         if ws is None or ws.numel() < nb or ws.device != w.device:
-            ws = cache[key] = torch.empty(int(nb), dtype=torch.uint8, device=w.device)
+            # zeroed: behind the weight image a dgrad workspace holds the zero-padded dY planes, whose borders nobody
+            # writes when the producer of dY fills the interiors itself (padded_dy_view / conv2d_dgrad(dy_prepadded))
+            ws = cache[key] = torch.zeros(int(nb), dtype=torch.uint8, device=w.device)
         jobs.append(_hip.ConvPackJob(w.data_ptr(), ws.data_ptr(), ws.numel(), C, hw, hw, OC, KH, KW, stride,
                                      1 if dgrad else 0))
         out[key] = ws
@@ -142,22 +144,44 @@ def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=N
     _hip.check(rc, 'acktr_conv2d_wgrad_f32')
 
 
-def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None):
-    """dx = conv_transpose(dy, w) * (x_act > 0); x_act [B,C,H,W] is the (post-ReLU) input of the layer."""
+def padded_dy_view(packed, B, w, stride, in_hw):
+    """The zero-padded dY region ([B, OC, 11, 11] fp32) inside a stationary-dgrad workspace from pack_conv_weights, or
+    None.  A producer of that layer's dY (linear_dgrad / conv2d_dgrad with padded_out=) writes the interiors there and
+    conv2d_dgrad(..., dy_prepadded=True) then skips its padding pass; the borders stay zero from the allocation."""
+    if packed is None:
+        return None
+    OC, C, KH, KW = w.shape
+    off = _hip.lib().acktr_conv2d_dgrad_padded_dy_offset_bytes(C, in_hw, in_hw, OC, KH, KW, stride)
+    n = B * OC * 121
+    if off < 0 or off % 4 or packed.numel() < off + 4 * n:
+        return None
+    return packed[off:off + 4 * n].view(f32).view(B, OC, 11, 11)
+
+
+def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None, dy_prepadded=False, padded_out=None):
+    """dx = conv_transpose(dy, w) * (x_act > 0); x_act [B,C,H,W] is the (post-ReLU) input of the layer.
+    dy_prepadded: `packed` already holds this dY zero-padded (see padded_dy_view); padded_out [B,C,H+2p,W+2p]: dx is
+    also written there, interior only."""
     OC, C, KH, KW = w.shape
     B, _, OH, OW = dy.shape
     H, W = (OH - 1) * stride + KH, (OW - 1) * stride + KW
     if out is None:
         out = torch.empty(B, C, H, W, dtype=f32, device=dy.device)
     assert out.shape == (B, C, H, W) and (x_act is None or x_act.shape == out.shape)
+    pad = 0
+    if padded_out is not None:
+        pad = (padded_out.shape[-1] - W) // 2
+        assert padded_out.shape == (B, C, H + 2 * pad, W + 2 * pad) and pad > 0
+    assert not dy_prepadded or packed is not None
     L = _hip.lib()
     ws = packed if packed is not None else \
         workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride), tag='dgrad')
     with _Timed('conv%ds%d_dgrad' % (KH, stride), 2.0 * dy.numel() * C * KH * KW):
-        rc = L.acktr_conv2d_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
-                                      B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),
-                                      1 if packed is not None else 0, _hip.cur_stream(dy.device))
-    _hip.check(rc, 'acktr_conv2d_dgrad_f32')
+        rc = L.acktr_conv2d_dgrad_ex_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
+                                         B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),
+                                         (1 if packed is not None else 0) | (2 if dy_prepadded else 0),
+                                         _p(padded_out, 'dx_padded'), pad, _hip.cur_stream(dy.device))
+    _hip.check(rc, 'acktr_conv2d_dgrad_ex_f32')
     return out
 
 
@@ -181,18 +205,26 @@ def linear_fwd(x, w, bias, act=None, out=None):
     return out
 
 
-def linear_dgrad(dy, w, gate_src=None, gate=None, out=None, accumulate=False):
+def linear_dgrad(dy, w, gate_src=None, gate=None, out=None, accumulate=False, padded_out=None, planes=None):
+    """padded_out [B, C, OH+2p, OW+2p] with planes=(C, OH, OW): dx is also written there as zero-padded planes
+    (interior only) -- the dY layout of the conv dgrad that follows an FC layer."""
     B, OUT = dy.shape
     IN = w.shape[1]
     assert w.shape[0] == OUT
     if out is None:
         assert not accumulate
         out = torch.empty(B, IN, dtype=f32, device=dy.device)
+    C = OH = OW = pad = 0
+    if padded_out is not None:
+        C, OH, OW = planes
+        pad = (padded_out.shape[-1] - OW) // 2
+        assert C * OH * OW == IN and pad > 0 and padded_out.shape == (B, C, OH + 2 * pad, OW + 2 * pad)
     with _Timed('linear%dx%d_dgrad' % (IN, OUT), 2.0 * B * IN * OUT):
-        rc = _hip.lib().acktr_linear_dgrad_f32(_p(dy, 'dy'), _p(w, 'w'), _p(gate_src, 'gate_src'), ACT[gate],
-                                               _p(out, 'dx'), B, IN, OUT, 1 if accumulate else 0,
-                                               _hip.cur_stream(dy.device))
-    _hip.check(rc, 'acktr_linear_dgrad_f32')
+        rc = _hip.lib().acktr_linear_dgrad_ex_f32(_p(dy, 'dy'), _p(w, 'w'), _p(gate_src, 'gate_src'), ACT[gate],
+                                                  _p(out, 'dx'), B, IN, OUT, 1 if accumulate else 0,
+                                                  _p(padded_out, 'dx_padded'), C, OH, OW, pad,
+                                                  _hip.cur_stream(dy.device))
+    _hip.check(rc, 'acktr_linear_dgrad_ex_f32')
     return out
 
 

@@ -356,10 +356,26 @@ extern "C" long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, i
     return dgrad_ws_floats(B, C, H, W, OC, KH, KW, S) * (long)sizeof(float);
 }
 
+extern "C" long acktr_conv2d_dgrad_padded_dy_offset_bytes(int C, int H, int W, int OC, int KH, int KW, int S) {
+    const int geom = geom_of(H, W, KH, KW, S);
+    if (geom == GEOM_NONE || !sw_dgrad_ok(geom, C, OC)) return -1;
+    return sw_dgrad_image_floats(geom, OC) * (long)sizeof(float);
+}
+
 extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C,
                                       int H, int W, int OC, int KH, int KW, int S, void* workspace,
                                       long workspace_bytes, int prepacked, void* stream) {
-    ACKTR_ARG(dy && w && dx, "conv2d_dgrad: null pointer");
+    return acktr_conv2d_dgrad_ex_f32(dy, w, x_act, dx, B, C, H, W, OC, KH, KW, S, workspace, workspace_bytes, prepacked,
+                                     nullptr, 0, stream);
+}
+
+extern "C" int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C,
+                                         int H, int W, int OC, int KH, int KW, int S, void* workspace,
+                                         long workspace_bytes, int flags, float* dx_padded, int pad, void* stream) {
+    const int prepacked = flags & 1;
+    const bool prepadded = (flags & 2) != 0;      // the zero-padded dY already sits in the workspace (a producer wrote it)
+    ACKTR_ARG((dy || prepadded) && w && dx, "conv2d_dgrad: null pointer");
+    ACKTR_ARG(!dx_padded || (pad > 0 && pad <= 4), "conv2d_dgrad: dx_padded needs 1 <= pad <= 4");
     const bool gather_ok = false;
     CONV_COMMON_CHECKS("conv2d_dgrad");
     ACKTR_ARG(workspace && workspace_bytes >= dgrad_ws_floats(B, C, H, W, OC, KH, KW, S) * (long)sizeof(float),
@@ -372,11 +388,14 @@ extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const flo
         float* dyp = wp + sw_dgrad_image_floats(geom, OC);
         const long planes = (long)B * OC;
         const unsigned pgrid = (unsigned)((planes + 7) / 8);
-        if (geom == GEOM_4S2) hipLaunchKernelGGL((sw_pad_kernel<9, 9, 1>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
-        else hipLaunchKernelGGL((sw_pad_kernel<7, 7, 2>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
-        ACKTR_LAUNCH_CHECK();
+        if (!prepadded) {
+            if (geom == GEOM_4S2) hipLaunchKernelGGL((sw_pad_kernel<9, 9, 1>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
+            else hipLaunchKernelGGL((sw_pad_kernel<7, 7, 2>), dim3(pgrid), dim3(256), 0, s, dy, dyp, planes);
+            ACKTR_LAUNCH_CHECK();
+        }
         int rc = 0;
         if (geom == GEOM_4S2) {
+            ACKTR_ARG(!dx_padded, "conv2d_dgrad: dx_padded is only produced by the 3x3 stride-1 stationary path");
             if (!prepacked) rc = launch_sw_pack<SwD2>(w, img, 4 * C, 1, C, 2, s);
             if (rc) return rc;
             SwPhase2Epi<10, 10, 20, 20> epi{dx, x_act};
@@ -384,9 +403,11 @@ extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const flo
         }
         if (!prepacked) rc = launch_sw_pack<SwD3>(w, img, C, 1, C, 1, s);
         if (rc) return rc;
-        SwGateEpi<81> epi{dx, x_act, C};
+        const int pw = W + 2 * pad;
+        SwGateEpi<81> epi{dx, x_act, C, dx_padded, W, pw, (H + 2 * pad) * pw, pad * pw + pad};
         return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s);
     }
+    ACKTR_ARG(!prepadded && !dx_padded, "conv2d_dgrad: padded operands need the stationary-weight path (this shape runs the tile GEMM)");
 #define DG(KH_, KW_, S_, OH_, OW_)                                                                 \
     (C <= 32 ? conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 32, 1, 4>(dy, w, x_act, dx, B, C, OC, wp, s)   \
              : conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 64, 2, 2>(dy, w, x_act, dx, B, C, OC, wp, s))

@@ -191,11 +191,15 @@ struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
 template <int SP>
 struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
     float* dx; const float* xact; int M;
+    // optional second copy of dX in the zero-padded plane layout the NEXT layer's dgrad reads ([b][m][psz] planes of
+    // rows pw long, interior origin at poff0, the layer's own rows ow long): saves that layer's padding pass
+    float* dxp; int ow, pw, psz, poff0;
     template <int TM>
     __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM]) const {
         const int m0 = 32 * TM * mg;
         if (!valid || m0 >= M) return;
         const long off = (long)(r / SP) * M * SP + (r % SP);
+        const long offp = dxp ? (long)(r / SP) * M * psz + ((r % SP) / ow) * pw + ((r % SP) % ow) + poff0 : 0;
         const bool full = (M % 32 == 0);
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
@@ -209,7 +213,10 @@ struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
             for (int g = 0; g < 16; ++g) {
                 const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
                 const float v = gv[g] > 0.f ? acc[a][g] : 0.f;
-                if (full || m < M) dx[off + (long)m * SP] = v;
+                if (full || m < M) {
+                    dx[off + (long)m * SP] = v;
+                    if (dxp) dxp[offp + (long)m * psz] = v;
+                }
             }
         }
     }

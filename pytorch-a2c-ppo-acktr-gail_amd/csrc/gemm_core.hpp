@@ -452,15 +452,21 @@ struct RowMajorEpi {
     float* rowsum_dst; long rowsum_stride;                     // optional: rowsum_dst[slab*stride + m] = sum_k Mop(m, k)
     int symmetric;                                             // C = X X^T: tiles strictly below the diagonal are skipped;
                                                                // the caller mirrors the upper triangle afterwards
+    // optional second copy of C with every row read as [ch][oh][ow] planes (c2_sp = oh*ow) and written zero-padded:
+    // c2[m*ldc2 + ch*c2_psz + y*c2_pw + x + c2_off0] -- the layout the conv dgrad behind an FC dgrad reads
+    float* c2; long ldc2; int c2_sp, c2_ow, c2_pw, c2_psz, c2_off0;
     static constexpr bool HAS_ROWSUM = true;
     __device__ __forceinline__ bool wants_rowsum() const { return rowsum_dst != nullptr; }
     __device__ __forceinline__ void rowsum(int m, float v, int ks) const {
         if (m < M) rowsum_dst[(long)ks * rowsum_stride + m] = v;
     }
-    struct Col { int n; int ok; float bn; float dn; };
+    struct Col { int n; int ok; float bn; float dn; int off2; };
     __device__ __forceinline__ Col col(int n) const {
         Col cc; cc.n = n; cc.ok = n < N; cc.bn = (cc.ok && bias_n) ? bias_n[n] : 0.f;
-        cc.dn = (cc.ok && div_n) ? div_n[n] : 0.f; return cc;
+        cc.dn = (cc.ok && div_n) ? div_n[n] : 0.f;
+        cc.off2 = 0;
+        if (c2 && cc.ok) { const int ch = n / c2_sp, e = n % c2_sp; cc.off2 = ch * c2_psz + (e / c2_ow) * c2_pw + e % c2_ow + c2_off0; }
+        return cc;
     }
     __device__ __forceinline__ void st(const Col& cc, int m, float acc, int ks) const {
         if (!cc.ok || m >= M) return;
@@ -474,6 +480,7 @@ struct RowMajorEpi {
         float* d = c + (long)ks * slab_stride + (long)m * ldc + cc.n;
         if (accumulate) v += *d;
         *d = v;
+        if (c2) c2[(long)m * ldc2 + cc.off2] = v;
     }
 };
 template <>
@@ -486,6 +493,7 @@ static inline RowMajorEpi row_major_epi(float* c, int M, int N, long ldc) {
     RowMajorEpi e; e.c = c; e.M = M; e.N = N; e.ldc = ldc; e.slab_stride = 0; e.bias_n = nullptr; e.bias_m = nullptr;
     e.scale = 1.f; e.act = 0; e.gate_src = nullptr; e.ldg = 0; e.gate = 0; e.accumulate = 0;
     e.div_m = nullptr; e.div_n = nullptr; e.div_add = 0.f; e.rowsum_dst = nullptr; e.rowsum_stride = 0; e.symmetric = 0;
+    e.c2 = nullptr; e.ldc2 = 0; e.c2_sp = 1; e.c2_ow = 1; e.c2_pw = 0; e.c2_psz = 0; e.c2_off0 = 0;
     return e;
 }
 

@@ -435,10 +435,19 @@ extern "C" int acktr_linear_fwd_f32(const float* x, const float* w, const float*
 
 extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx,
                                       int B, int IN, int OUT, int accumulate, void* stream) {
+    return acktr_linear_dgrad_ex_f32(dy, w, gate_src, gate, dx, B, IN, OUT, accumulate, nullptr, 0, 0, 0, 0, stream);
+}
+
+extern "C" int acktr_linear_dgrad_ex_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx,
+                                         int B, int IN, int OUT, int accumulate, float* dx_padded, int C, int OH, int OW,
+                                         int pad, void* stream) {
     ACKTR_ARG(dy && w && dx, "linear_dgrad: null pointer");
     ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_dgrad: bad sizes");
     ACKTR_ARG(gate >= 0 && gate <= 2 && (gate == 0 || gate_src), "linear_dgrad: gate needs gate_src");
-    if (skinny_ok(w, dx, gate_src, IN, OUT)) {
+    ACKTR_ARG(!dx_padded || (C > 0 && OH > 0 && OW > 0 && pad > 0 && pad <= 4 && (long)C * OH * OW == IN && OUT > SK_MAX_OUT &&
+                             (long)B * C * (OH + 2 * pad) * (OW + 2 * pad) < (1L << 31)),
+              "linear_dgrad: dx_padded needs IN == C*OH*OW, 1 <= pad <= 4 and OUT > %d", SK_MAX_OUT);
+    if (!dx_padded && skinny_ok(w, dx, gate_src, IN, OUT)) {
         hipLaunchKernelGGL(skinny_dgrad_kernel, dim3(cdiv((long)B * (IN / 4), 256)), dim3(256), 0, (hipStream_t)stream,
                            dy, w, gate_src, gate, dx, B, IN, OUT, accumulate);
         ACKTR_LAUNCH_CHECK();
@@ -446,6 +455,11 @@ extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const flo
     }
     RowMajorEpi e = row_major_epi(dx, B, IN, IN);
     e.gate = gate; e.gate_src = gate_src; e.ldg = IN; e.accumulate = accumulate;
+    if (dx_padded) {                       // second copy as zero-padded [B, C, OH+2p, OW+2p] planes (interior only)
+        const int pw = OW + 2 * pad, psz = (OH + 2 * pad) * pw;
+        e.c2 = dx_padded; e.ldc2 = (long)C * psz; e.c2_sp = OH * OW; e.c2_ow = OW; e.c2_pw = pw; e.c2_psz = psz;
+        e.c2_off0 = pad * pw + pad;
+    }
     // dX[b, i] = sum_o dY[b, o] * W[o, i]   : A = dY (k contiguous), B(n=i, k=o) = W[o*IN + i] (row contiguous)
     return gemm_rowmajor(dy, OUT, 1, w, 1, IN, e, B, IN, OUT, 1, (hipStream_t)stream);
 }

@@ -312,3 +312,39 @@ def test_head_step_matches_layer_path(B, A, algo_id, gather):
         err = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
         assert err < 2e-5, '%s: fused vs layer path rel err %g' % (name, err)
     assert np.array_equal(out[1][2] == 0, out[0][2] == 0) or (out[1][2] != 0).sum() > 0
+
+
+@pytest.mark.parametrize('B', [5, 96])
+def test_folded_dgrad_padding_is_bit_identical(B):
+    """The zero-padded dY copies written by the producers' epilogues (FC dgrad -> conv3 dgrad -> conv2 dgrad,
+    engine.FOLD_PAD) against the separate padding passes: the same values reach the same kernels, so every gradient
+    must match bit for bit -- also when the batch shrinks inside an already allocated (larger) workspace."""
+    from a2c_ppo_acktr import engine
+    from a2c_ppo_acktr.model import Policy
+    torch.manual_seed(17)
+    pol = Policy((4, 84, 84), Discrete(6))
+    pol.to('cuda')
+    g = torch.Generator(device='cuda').manual_seed(B)
+    res = []
+    for nb in (B, max(B // 2, 1)):
+        obs = torch.randint(0, 256, (nb, 4, 84, 84), device='cuda', generator=g).float()
+        act = torch.randint(0, 6, (nb,), device='cuda', generator=g)
+        olp = 0.1 * torch.randn(nb, device='cuda', generator=g) - 1.7
+        vp, ret, adv = (torch.randn(nb, device='cuda', generator=g) for _ in range(3))
+        for fold in (True, False):
+            engine.FOLD_PAD = fold
+            try:
+                gflat = torch.full_like(pol.flat_params, 3.0)
+                with torch.no_grad():
+                    acts = engine.forward(pol, obs, head=False)
+                    engine.head_step(pol, acts, engine.ALGO_PPO, act, torch.zeros(3, device='cuda'), 1.0 / nb, old_logp=olp,
+                                     old_values=vp, returns=ret, adv=adv, clip=0.1, value_coef=0.5, entropy_coef=0.01,
+                                     gflat=gflat)
+                    engine.backward(pol, acts, gflat, keep=True)
+                assert (acts.pd3 is not None) == fold and (acts.pd2 is not None) == fold
+                res.append((gflat.clone(), acts.dy1.clone(), acts.dy2.clone()))
+            finally:
+                engine.FOLD_PAD = True
+        for a, b in zip(res[-2], res[-1]):
+            assert torch.equal(a, b)
+        assert float(res[-1][0].abs().max()) > 0 and bool(torch.isfinite(res[-1][0]).all())

@@ -303,8 +303,10 @@ def side_metrics(device):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=5)
-    ap.add_argument('--warmup', type=int, default=2)
+    # defaults: 20 timed updates (~0.2 s) behind 5 warm-up updates -- with 5 / 2 the 50 ms timed window showed +-4 %
+    # run-to-run swings on a cold box (clock ramp, one slow replay), far more than any kernel change this round
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-side-metrics', action='store_true')
     ap.add_argument('--force-dp', action='store_true',
@@ -383,9 +385,9 @@ def main():
         roof = None
         traffic, traffic_src = None, None
         try:      # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py)
-            tp = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic_v8.json')
+            tp = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic_v16.json')
             traffic = json.load(open(tp))[dom[0]]['traffic_bytes']
-            traffic_src = 'profiles/r1_pmc_traffic_v8.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)'
+            traffic_src = 'profiles/r1_pmc_traffic_v16.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)'
         except Exception:
             pass
         if dom[0] is not None:

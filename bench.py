@@ -313,6 +313,12 @@ def main():
                     help='one rank, but through the data-parallel code path on RCCL (rehearsal of the N>1 path)')
     args = ap.parse_args()
 
+    # stdout carries exactly ONE line, the JSON record: everything else that lands on file descriptor 1 -- RCCL prints
+    # a version banner there from C when a communicator is created -- is sent to stderr for the rest of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -431,7 +437,8 @@ def main():
             torch.set_num_threads(nthr)
             cb1['value'] = round(cb1['value'], 1)
             out['cpu_baseline_1thread'] = cb1
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + '\n').encode())
     if world > 1 or args.force_dp:
         dist.barrier()
         dist.destroy_process_group()

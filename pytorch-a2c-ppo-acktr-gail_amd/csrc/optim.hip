@@ -34,8 +34,17 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const float*
 __device__ __forceinline__ float clip_coef_from(const double* partial, int nparts, float max_norm, float* sm2,
                                                 float* norm_out) {
     if (threadIdx.x < 64) {
+        // nparts <= OPT_MAX_PARTIALS = 16 * 64: a fixed, fully unrolled trip count keeps the lane's (up to) 16 loads in
+        // flight together -- with a run-time bound they were 14 dependent L2 round trips in front of every workgroup
+        double v[OPT_MAX_PARTIALS / 64];
+#pragma unroll
+        for (int j = 0; j < OPT_MAX_PARTIALS / 64; ++j) {
+            const int i = threadIdx.x + 64 * j;
+            v[j] = partial[i < nparts ? i : 0];
+        }
         double s = 0.0;
-        for (int i = threadIdx.x; i < nparts; i += 64) s += partial[i];
+#pragma unroll
+        for (int j = 0; j < OPT_MAX_PARTIALS / 64; ++j) s += (threadIdx.x + 64 * j < nparts) ? v[j] : 0.0;
         s = wave_sum(s);
         if (threadIdx.x == 0) {
             const float total = (float)sqrt(s);

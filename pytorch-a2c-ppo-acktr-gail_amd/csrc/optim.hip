@@ -88,24 +88,28 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
         eps = hyper_dev[3];
         if (MODE == 0) {
             beta1 = hyper_dev[1]; beta2 = hyper_dev[2];
-            // torch/optim/adam.py:529-535 evaluates these in host doubles; one lane per workgroup does (a double pow
-            // per lane cost more than the whole update), the rest read them from LDS
-            if (threadIdx.x == 0) {
-                const int t = *step_dev;
-                const double bc1 = 1.0 - pow((double)beta1, (double)t);
-                const double bc2 = 1.0 - pow((double)beta2, (double)t);
+            // torch/optim/adam.py:529-535 evaluates these in host doubles; one lane per pow does (a double pow per lane
+            // cost more than the whole update), the rest read them from LDS.  The two lanes sit in waves 1 and 2, so the
+            // pows run beside each other and beside wave 0's sum of the norm partials, behind ONE barrier.
+            if (threadIdx.x == 64) {
+                const double bc1 = 1.0 - pow((double)beta1, (double)*step_dev);
                 sm_adam[0] = (float)((double)lr / bc1);
+            }
+            if (threadIdx.x == 128) {
+                const double bc2 = 1.0 - pow((double)beta2, (double)*step_dev);
                 sm_adam[1] = (float)sqrt(bc2);
             }
-            __syncthreads();
-            lr_or_step = sm_adam[0];
-            bc2_sqrt = sm_adam[1];
         } else {
             beta2 = hyper_dev[1];
             lr_or_step = lr;
         }
     }
-    if (use_clip) coef = clip_coef_from(partial, nparts, max_norm, sm2, norm_out);
+    if (use_clip) coef = clip_coef_from(partial, nparts, max_norm, sm2, norm_out);     // ends on a barrier
+    else __syncthreads();
+    if (hyper_dev && MODE == 0) {
+        lr_or_step = sm_adam[0];
+        bc2_sqrt = sm_adam[1];
+    }
     auto upd = [&](float& pi, float& gi, float& a1, float& a2) {
         if (use_clip) gi = gi * coef;
         if (MODE == 0) {

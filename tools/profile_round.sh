@@ -18,3 +18,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 rm -rf $OUT/kt
 python3 tools/pmc_traffic.py $OUT/pmc_FETCH_SIZE.csv $OUT/pmc_WRITE_SIZE.csv $OUT/pmc_traffic.json
+# optional third argument "sq": one more pass with the SQ activity counters (7 SQ_ + 1 GRBM_, inside the per-block limits)
+if [ "$2" = "sq" ]; then
+    timeout -s KILL 300 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES --output-format csv -d $OUT/SQ -o pmc -- $BENCH > $OUT/SQ.log 2>&1
+    python3 tools/pmc_summary.py $(find $OUT/SQ -name '*counter_collection.csv' | head -1) $OUT/pmc_SQ.csv
+    rm -rf $OUT/SQ
+fi

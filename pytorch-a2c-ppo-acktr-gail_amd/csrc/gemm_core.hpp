@@ -127,6 +127,12 @@ struct OperandTile {
 // Symmetric outputs (C = X X^T, the KFAC factors): an epilogue may declare a tile redundant -- every element of it lies
 // strictly below the diagonal; launch_symmetrize_lower() fills the lower triangle from the upper one at the end
 // (mirroring inside the epilogue was tried first: its column-strided stores cost what the skipped tiles saved).
+// Epilogues that declare GATE_PREFETCH offer pre(col, m) -> float and take that value as st()'s last argument.
+template <class Epi, class = void>
+struct EpiGatePrefetch : std::false_type {};
+template <class Epi>
+struct EpiGatePrefetch<Epi, std::enable_if_t<Epi::GATE_PREFETCH>> : std::true_type {};
+
 template <class Epi>
 struct EpiSym {
     __device__ static __forceinline__ bool skip(const Epi&, int, int, int) { return false; }
@@ -299,8 +305,16 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int mb = m0 + wm * (TM * 32) + a * 32 + 4 * lh;
+            if constexpr (EpiGatePrefetch<Epi>::value) {
+                float h[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], vz);
+                for (int r = 0; r < 16; ++r) h[r] = epi.pre(col, mb + (r & 3) + 8 * (r >> 2));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], vz, h[r]);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], vz);
+            }
         }
     }
 }
@@ -468,15 +482,22 @@ struct RowMajorEpi {
         if (c2 && cc.ok) { const int ch = n / c2_sp, e = n % c2_sp; cc.off2 = ch * c2_psz + (e / c2_ow) * c2_pw + e % c2_ow + c2_off0; }
         return cc;
     }
-    __device__ __forceinline__ void st(const Col& cc, int m, float acc, int ks) const {
+    // The gate operand of the 16 rows a lane stores is fetched by the kernel BEFORE the first store (GATE_PREFETCH):
+    // inside st() every load sat behind the previous row's stores, which the compiler cannot prove disjoint from it --
+    // sixteen dependent round trips per lane in the epilogue of every gated dgrad.
+    static constexpr bool GATE_PREFETCH = true;
+    __device__ __forceinline__ float pre(const Col& cc, int m) const {
+        return (gate && cc.ok && m < M) ? gate_src[(long)m * ldg + cc.n] : 1.f;
+    }
+    __device__ __forceinline__ void st(const Col& cc, int m, float acc, int ks, float h) const {
         if (!cc.ok || m >= M) return;
         float v = acc * scale + cc.bn;
         if (bias_m) v += bias_m[m];
         if (div_m) v = v / (div_m[m] * cc.dn + div_add);
         if (act == 1) v = v > 0.f ? v : 0.f;
         else if (act == 2) v = tanhf(v);
-        if (gate == 1) v = gate_src[(long)m * ldg + cc.n] > 0.f ? v : 0.f;
-        else if (gate == 2) { const float h = gate_src[(long)m * ldg + cc.n]; v = v * (1.f - h * h); }
+        if (gate == 1) v = h > 0.f ? v : 0.f;
+        else if (gate == 2) v = v * (1.f - h * h);
         float* d = c + (long)ks * slab_stride + (long)m * ldc + cc.n;
         if (accumulate) v += *d;
         *d = v;

@@ -391,9 +391,9 @@ def main():
         roof = None
         traffic, traffic_src = None, None
         try:      # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py)
-            tp = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic_v28.json')
+            tp = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic_v34.json')
             traffic = json.load(open(tp))[dom[0]]['traffic_bytes']
-            traffic_src = 'profiles/r1_pmc_traffic_v28.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)'
+            traffic_src = 'profiles/r1_pmc_traffic_v34.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)'
         except Exception:
             pass
         if dom[0] is not None:

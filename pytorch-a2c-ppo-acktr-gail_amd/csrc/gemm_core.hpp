@@ -305,12 +305,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
             const int mb = m0 + wm * (TM * 32) + a * 32 + 4 * lh;
-            if constexpr (EpiGatePrefetch<Epi>::value) {
+            if constexpr (EpiGatePrefetch<Epi>::value && TM * TN <= 2) {
                 float h[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) h[r] = epi.pre(col, mb + (r & 3) + 8 * (r >> 2));
 #pragma unroll
                 for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], vz, h[r]);
+            } else if constexpr (EpiGatePrefetch<Epi>::value) {
+                // 128x128 tiles (the KFAC factor SYRKs): the unrolled epilogue would keep all 64 prefetched values live
+                // on top of 64 accumulators -- 276 VGPRs, one wave per SIMD instead of two.  Load at the point of use.
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mb + (r & 3) + 8 * (r >> 2);
+                    epi.st(col, m, acc[a][b][r], vz, epi.pre(col, m));
+                }
             } else {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) epi.st(col, mb + (r & 3) + 8 * (r >> 2), acc[a][b][r], vz);

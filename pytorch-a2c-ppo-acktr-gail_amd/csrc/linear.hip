@@ -34,15 +34,22 @@ __global__ __launch_bounds__(256) void slab_reduce4_kernel(float* dst, const flo
             acc = acc + a; acc = acc + b; acc = acc + c; acc = acc + d;
         }
         for (; k < s1; ++k) acc = acc + *reinterpret_cast<const f32x4*>(slabs + (long)k * stride + 4 * i);
+        // epilogue operands first, ONE 16-byte store last (a load behind a may-alias store cannot be hoisted over it)
+        f32x4 bv = zero4(), prev = zero4();
+        if (bias) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bv[j] = bias[(4 * i + j) % ncols];
+        }
+        if (accumulate) prev = *reinterpret_cast<const f32x4*>(out + 4 * i);
+        f32x4 res;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            float v = acc[j] * scale;
-            if (bias) v += bias[(4 * i + j) % ncols];
+            float v = acc[j] * scale + bv[j];
             if (act == 1) v = v > 0.f ? v : 0.f;
             else if (act == 2) v = tanhf(v);
-            if (accumulate) v += out[4 * i + j];
-            out[4 * i + j] = v;
+            res[j] = v + prev[j];
         }
+        *reinterpret_cast<f32x4*>(out + 4 * i) = res;
     }
 }
 
@@ -73,15 +80,21 @@ __global__ __launch_bounds__(256) void slab_reduce_wave_kernel(float* __restrict
         acc[j] = v;
     }
     if (sub != 0 || i >= n4) return;
+    f32x4 bv = zero4(), prev = zero4();
+    if (bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bv[j] = bias[(4 * i + j) % ncols];
+    }
+    if (accumulate) prev = *reinterpret_cast<const f32x4*>(dst + 4 * i);
+    f32x4 res;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float v = acc[j] * scale;
-        if (bias) v += bias[(4 * i + j) % ncols];
+        float v = acc[j] * scale + bv[j];
         if (act == 1) v = v > 0.f ? v : 0.f;
         else if (act == 2) v = tanhf(v);
-        if (accumulate) v += dst[4 * i + j];
-        dst[4 * i + j] = v;
+        res[j] = v + prev[j];
     }
+    *reinterpret_cast<f32x4*>(dst + 4 * i) = res;
 }
 
 int launch_slab_reduce_ex(float* dst, const float* slabs, int nslabs, long n, long stride, float scale, int accumulate,

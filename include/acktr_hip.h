@@ -49,6 +49,16 @@ long acktr_adv_normalize_workspace_bytes(void);
 int acktr_adv_normalize_f32(const float* returns, const float* value_preds, float* adv, long n, void* workspace,
                             void* stream);
 
+/* The same normalisation for callers that cannot allocate (code under hipGraph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  NO counterpart in the reference.  It takes no workspace: the block partials
+ * live in a 16 KiB file-scope __device__ array of the library (one copy per GPU, held until the process ends),
+ * whose per-device address is looked up once with hipGetSymbolAddress.  The call itself allocates and frees nothing.
+ * Same kernels, same fixed reduction order -> bit-identical to acktr_adv_normalize_f32.  n must be
+ * <= acktr_adv_normalize_noalloc_max_n() (2^28 elements), else -1 with a message.  All calls on one GPU share that
+ * array: calls that overlap on one GPU (different streams) race; nothing in it has to start at zero. */
+long acktr_adv_normalize_noalloc_max_n(void);
+int acktr_adv_normalize_noalloc_f32(const float* returns, const float* value_preds, float* adv, long n, void* stream);
+
 /* Minibatch gather -- a2c_ppo_acktr/storage.py:127-140 (x.view(-1, ...)[indices]).
  * dst[i,:] = src[idx[i],:], rows of row_bytes bytes (multiple of 4); idx on device, 0 <= idx < src_rows. */
 int acktr_gather_rows(const void* src, const int64_t* idx, void* dst, long rows, long row_bytes, long src_rows,

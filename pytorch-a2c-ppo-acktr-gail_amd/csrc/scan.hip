@@ -16,6 +16,8 @@
 // products and sums are rounded separately, exactly as the reference's separate torch ops do.
 // Plain operators are used on purpose: the __f*_rn() header wrappers are compiled under the
 // header's own contraction mode and DO fuse into v_fma after inlining.
+#include <mutex>
+
 #include "common.hpp"
 #include "../../include/acktr_hip.h"
 
@@ -292,23 +294,71 @@ extern "C" int acktr_compute_returns_f32(const float* rewards, float* value_pred
 
 extern "C" long acktr_adv_normalize_workspace_bytes(void) { return (long)ADV_MAX_BLOCKS * 2 * sizeof(double); }
 
-extern "C" int acktr_adv_normalize_f32(const float* returns, const float* value_preds, float* adv, long n,
-                                       void* workspace, void* stream) {
-    ACKTR_ARG(returns && value_preds && adv && workspace, "adv_normalize: null pointer");
-    ACKTR_ARG(n >= 2, "adv_normalize: need n >= 2 for the unbiased std (n=%ld)", n);
-    hipStream_t s = (hipStream_t)stream;
+namespace acktr {
+static int adv_normalize_launch(const float* returns, const float* value_preds, float* adv, long n, double* partial,
+                                hipStream_t s) {
     int blocks = cdiv(n, ADV_THREADS * 8);
     if (blocks > ADV_MAX_BLOCKS) blocks = ADV_MAX_BLOCKS;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(adv_partial_kernel, dim3(blocks), dim3(ADV_THREADS), 0, s, returns, value_preds, n,
-                       (double*)workspace);
+    hipLaunchKernelGGL(adv_partial_kernel, dim3(blocks), dim3(ADV_THREADS), 0, s, returns, value_preds, n, partial);
     ACKTR_LAUNCH_CHECK();
     int nblocks2 = cdiv(n, ADV_THREADS * 4);
     if (nblocks2 > 2048) nblocks2 = 2048;
     hipLaunchKernelGGL(adv_normalize_kernel, dim3(nblocks2), dim3(ADV_THREADS), 0, s, returns, value_preds, adv, n,
-                       (const double*)workspace, blocks);
+                       (const double*)partial, blocks);
     ACKTR_LAUNCH_CHECK();
     return 0;
+}
+
+// Scratch of the allocation-free entry point: the (sum, sum of squares) partials of at most ADV_MAX_BLOCKS blocks,
+// 16 KiB per GPU, resident for the life of the process.  The name is a host-side stand-in: host code only ever uses
+// the per-device address that hipGetSymbolAddress returns (each GPU has its own copy at its own address).
+static __device__ __align__(256) double adv_noalloc_scratch[ADV_MAX_BLOCKS * 2];
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static std::mutex g_noalloc_mu;
+static double* g_noalloc_ptr[NOALLOC_MAX_DEVICES] = {nullptr};
+
+static int adv_noalloc_scratch_ptr(double** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) { set_error("adv_normalize_noalloc: hipGetDevice failed: %s", hipGetErrorString(e)); return (int)e; }
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) { set_error("adv_normalize_noalloc: device %d out of range", dev); return -1; }
+    std::lock_guard<std::mutex> lk(g_noalloc_mu);
+    if (!g_noalloc_ptr[dev]) {                       // once per device, with that device current
+        double* p = nullptr;
+        e = hipGetSymbolAddress((void**)&p, HIP_SYMBOL(adv_noalloc_scratch));
+        if (e != hipSuccess || !p) {
+            set_error("adv_normalize_noalloc: hipGetSymbolAddress failed on device %d: %s", dev, hipGetErrorString(e));
+            return e != hipSuccess ? (int)e : -1;
+        }
+        g_noalloc_ptr[dev] = p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return 0;
+}
+}  // namespace acktr
+
+extern "C" int acktr_adv_normalize_f32(const float* returns, const float* value_preds, float* adv, long n,
+                                       void* workspace, void* stream) {
+    ACKTR_ARG(returns && value_preds && adv && workspace, "adv_normalize: null pointer");
+    ACKTR_ARG(n >= 2, "adv_normalize: need n >= 2 for the unbiased std (n=%ld)", n);
+    return adv_normalize_launch(returns, value_preds, adv, n, (double*)workspace, (hipStream_t)stream);
+}
+
+extern "C" long acktr_adv_normalize_noalloc_max_n(void) { return 1L << 28; }
+
+extern "C" int acktr_adv_normalize_noalloc_f32(const float* returns, const float* value_preds, float* adv, long n,
+                                               void* stream) {
+    ACKTR_ARG(returns && value_preds && adv, "adv_normalize_noalloc: null pointer");
+    ACKTR_ARG(n >= 2, "adv_normalize_noalloc: need n >= 2 for the unbiased std (n=%ld)", n);
+    ACKTR_ARG(n <= acktr_adv_normalize_noalloc_max_n(),
+              "adv_normalize_noalloc: n=%ld exceeds the maximum of %ld elements of this allocation-free entry point; "
+              "use acktr_adv_normalize_f32 with a caller workspace", n, acktr_adv_normalize_noalloc_max_n());
+    double* partial = nullptr;
+    int rc = adv_noalloc_scratch_ptr(&partial);
+    if (rc) return rc;
+    // every partial a launch reads was written by the same call's first kernel: nothing has to start at zero
+    return adv_normalize_launch(returns, value_preds, adv, n, partial, (hipStream_t)stream);
 }
 
 extern "C" int acktr_gather_rows(const void* src, const int64_t* idx, void* dst, long rows, long row_bytes,

@@ -1,0 +1,60 @@
+"""GPU: the allocation-free entry point acktr_adv_normalize_noalloc_f32 (include/acktr_hip.h) against the existing
+acktr_adv_normalize_f32, straight through the C-ABI.  Same kernels, same fixed-order reduction -> bit-identical.
+Two calls in a row share the library's per-GPU scratch array; the second uses a smaller input.  Collected last
+(file name), so a failure here cannot hide another test under `pytest -x`."""
+import pytest
+import torch
+
+from a2c_ppo_acktr import _hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _both(n, seed):
+    L = _hip.lib()
+    dev = torch.device('cuda:0')
+    g = torch.Generator().manual_seed(seed)
+    ret = torch.randn(n, generator=g).to(dev)
+    val = torch.randn(n, generator=g).to(dev)
+    stream = _hip.cur_stream(dev)
+    ws = torch.empty(L.acktr_adv_normalize_workspace_bytes(), dtype=torch.uint8, device=dev)
+    want = torch.full((n,), float('nan'), device=dev)
+    got = torch.full((n,), float('nan'), device=dev)
+    _hip.check(L.acktr_adv_normalize_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(want), n,
+                                         _hip.dev_ptr(ws), stream), 'acktr_adv_normalize_f32')
+    torch.cuda.synchronize()
+    before = torch.cuda.memory_allocated(dev)
+    _hip.check(L.acktr_adv_normalize_noalloc_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(got), n, stream),
+               'acktr_adv_normalize_noalloc_f32')
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated(dev) == before
+    return want, got
+
+
+def test_noalloc_adv_normalize_matches_workspace_form_twice():
+    # first call: enough elements for every one of the 1024 partial slots to be used (n > 1024 * 2048)
+    want, got = _both(128 * 32768 + 13, 1)
+    assert torch.isfinite(got).all()
+    assert torch.equal(want.view(torch.int32), got.view(torch.int32))
+    # second call, smaller input: only 3 partial slots are live, the rest still holds the first call's values
+    want, got = _both(128 * 32 + 5, 2)
+    assert torch.isfinite(got).all()
+    assert torch.equal(want.view(torch.int32), got.view(torch.int32))
+    # and the smallest legal one
+    want, got = _both(2, 3)
+    assert torch.equal(want.view(torch.int32), got.view(torch.int32))
+
+
+def test_noalloc_rejects_oversize_and_bad_arguments():
+    L = _hip.lib()
+    dev = torch.device('cuda:0')
+    x = torch.zeros(8, device=dev)
+    mx = L.acktr_adv_normalize_noalloc_max_n()
+    assert mx == 1 << 28
+    rc = L.acktr_adv_normalize_noalloc_f32(_hip.dev_ptr(x), _hip.dev_ptr(x), _hip.dev_ptr(x), mx + 1,
+                                           _hip.cur_stream(dev))
+    assert rc == -1 and b'exceeds the maximum' in L.acktr_last_error()
+    rc = L.acktr_adv_normalize_noalloc_f32(_hip.dev_ptr(x), _hip.dev_ptr(x), _hip.dev_ptr(x), 1, _hip.cur_stream(dev))
+    assert rc == -1
+    rc = L.acktr_adv_normalize_noalloc_f32(None, _hip.dev_ptr(x), _hip.dev_ptr(x), 8, _hip.cur_stream(dev))
+    assert rc == -1

@@ -98,7 +98,9 @@ def cpu_baseline(ro_cpu, seed, max_updates=12, budget_s=12.0):
     t0 = time.perf_counter()
     n_upd, losses = 0, None
     while n_upd < max_updates and (n_upd == 0 or time.perf_counter() - t0 < budget_s):   # bounded sample of host work
-        losses = algo_ref.ppo_update(P, opt, ro, **PPO_HP)
+        res = algo_ref.ppo_update(P, opt, ro, **PPO_HP)
+        if losses is None:
+            losses = res          # the FIRST update's (value_loss, action_loss, entropy): main() checks the GPU's against it
         n_upd += 1
     dt = time.perf_counter() - t0
     return dict(value=n_upd * T * N * PPO_HP['ppo_epoch'] / dt, unit='samples/s', cores=torch.get_num_threads(),
@@ -384,6 +386,7 @@ def main():
     torch.cuda.synchronize()
     scan_ms = ev0.elapsed_time(ev1) / 20
 
+    parity_ok = True
     if rank == 0:
         dom = max(prof.items(), key=lambda kv: kv[1]['total_ms']) if prof else (None, None)
         gemm_ms = sum(v['total_ms'] for v in prof.values())
@@ -391,9 +394,13 @@ def main():
         roof = None
         traffic, traffic_src = None, None
         try:      # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py)
-            tp = os.path.join(ROOT, 'profiles', 'r1_pmc_traffic_v34.json')
+            import glob
+            import re
+            cands = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic_*.json'))
+            key = lambda f: tuple(int(x) for x in re.findall(r'\d+', os.path.basename(f)))     # (round, version)
+            tp = max(cands, key=key)
             traffic = json.load(open(tp))[dom[0]]['traffic_bytes']
-            traffic_src = 'profiles/r1_pmc_traffic_v34.json (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)'
+            traffic_src = 'profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)' % os.path.basename(tp)
         except Exception:
             pass
         if dom[0] is not None:
@@ -427,9 +434,21 @@ def main():
                 out['side_metrics'] = dict(error=repr(e))
         if world == 1 and not args.no_cpu_baseline:
             keep = {k: v.cpu() for k, v in ro.items()}
-            cb, _ = cpu_baseline(keep, seed=7)
+            cb, cpu_losses = cpu_baseline(keep, seed=7)
             cb['value'] = round(cb['value'], 1)
             out['cpu_baseline'] = cb
+            # parity of what was timed: a FRESH agent (same initial weights, same CPU seed for the minibatch
+            # permutations) runs the oracle's first update on the GPU; the three returned losses must agree to the
+            # north_star bar (1e-4 relative)
+            pol_c, agent_c = build_agent(device, seed=7)
+            torch.manual_seed(7 + 1)
+            gpu_losses = agent_c.update(rs)
+            rel = [abs(a - b) / max(abs(b), 1e-3) for a, b in zip(gpu_losses, cpu_losses)]
+            out['parity_check'] = dict(what='first PPO.update from identical weights / rollouts / CPU seed: GPU losses vs '
+                                            'the cpu_baseline oracle run', gpu=[round(x, 7) for x in gpu_losses],
+                                       cpu=[round(x, 7) for x in cpu_losses], max_rel_err=float('%.3g' % max(rel)),
+                                       tol=1e-4, ok=bool(max(rel) <= 1e-4))
+            parity_ok = out['parity_check']['ok']
             # the reference itself runs single-threaded (main.py:38 torch.set_num_threads(1)): one update that way too
             nthr = torch.get_num_threads()
             torch.set_num_threads(1)
@@ -439,9 +458,13 @@ def main():
             out['cpu_baseline_1thread'] = cb1
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + '\n').encode())
+        if not parity_ok:
+            sys.stderr.write('bench.py: GPU losses differ from the CPU oracle: %r\n' % (out['parity_check'],))
     if world > 1 or args.force_dp:
         dist.barrier()
         dist.destroy_process_group()
+    if not parity_ok:
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -10,6 +10,7 @@ from . import _hip
 
 f32 = torch.float32
 _ws_cache = {}
+_ws_retired = []          # outgrown buffers, kept alive for captured graphs that still point into them
 
 # Optional per-launch timing with HIP events on the launch stream (used by bench.py for the roofline
 # figures).  `profiler` is None (off) or a dict name -> list of (start_event, end_event, work) tuples.
@@ -51,11 +52,18 @@ def profile_summary():
 
 
 def workspace(device, nbytes, tag='ws'):
-    """Per-(device, tag) scratch buffer, grown on demand and reused across calls."""
+    """Per-(device, tag) scratch buffer, grown on demand and reused across calls.
+
+    A buffer that is outgrown is RETIRED, never freed: hipGraphs captured earlier (PPO / A2C / ACKTR / GAIL steps)
+    hold raw pointers into it and keep replaying while another agent with larger shapes makes this cache grow.
+    Growth is at least 2x, so the retired buffers of a tag add up to less than its live one."""
     key = (str(device), tag)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            _ws_retired.append(buf)
+        want = max(int(nbytes), 1 << 20, 2 * buf.numel() if buf is not None else 0)
+        buf = torch.empty(want, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 

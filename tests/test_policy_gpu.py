@@ -348,3 +348,46 @@ def test_folded_dgrad_padding_is_bit_identical(B):
         for a, b in zip(res[-2], res[-1]):
             assert torch.equal(a, b)
         assert float(res[-1][0].abs().max()) > 0 and bool(torch.isfinite(res[-1][0]).all())
+
+
+def test_captured_graph_survives_workspace_growth():
+    """ops.workspace() hands out per-(device, tag) scratch that captured hipGraphs point into.  Agent A (small
+    minibatches) captures its step graph; agent B (larger minibatches) then makes every scratch buffer grow; A's
+    replay must still equal an eager run of the same updates bit for bit (outgrown buffers are retired, not freed)."""
+    from a2c_ppo_acktr import algo, ops
+    hp = dict(clip_param=0.1, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01, lr=2.5e-4,
+              eps=1e-5, max_grad_norm=0.5)
+
+    def run(use_graph, grow):
+        ops._ws_cache.clear()                       # start from empty caches so that B's shapes really outgrow A's
+        pol = make_policy('cnn', None, 6, 77)
+        ro = synth.make_rollouts(8, 4, (4, 84, 84), 'discrete', 6, salt=1700)
+        rs = make_storage(ro, (4, 84, 84), Discrete(6))
+        rs.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
+        agent = algo.PPO(pol, **hp)
+        agent.use_graph = use_graph
+        out = []
+        for it in range(4):
+            if it == 2 and grow:                    # A's graph exists (captured at update 1); now a bigger agent runs
+                assert (agent._graphs is not None) == use_graph
+                polb = make_policy('cnn', None, 6, 78)
+                rob = synth.make_rollouts(16, 24, (4, 84, 84), 'discrete', 6, salt=1701)
+                rsb = make_storage(rob, (4, 84, 84), Discrete(6))
+                rsb.compute_returns(t(rob['next_value']).cuda(), True, 0.99, 0.95, True)
+                agb = algo.PPO(polb, **hp)
+                before = {k: v.data_ptr() for k, v in ops._ws_cache.items()}
+                torch.manual_seed(5)
+                agb.update(rsb)
+                assert any(ops._ws_cache[k].data_ptr() != p for k, p in before.items()), 'no workspace grew'
+                del agb, polb, rsb
+                torch.cuda.empty_cache()
+                junk = [torch.full((1 << 20,), float('nan'), device='cuda') for _ in range(8)]   # recycle freed memory
+                del junk
+            torch.manual_seed(900 + it)
+            out.append(agent.update(rs))
+        return out, pol.flat_params.clone()
+
+    l_eager, p_eager = run(False, False)
+    l_graph, p_graph = run(True, True)
+    assert l_eager == l_graph
+    assert torch.equal(p_eager, p_graph)

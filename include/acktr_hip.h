@@ -264,6 +264,21 @@ typedef struct acktr_eig_job { float* a_inout_qt; float* d; int n; int reserved;
 int acktr_sym_eig_rocsolver_multi_f32(const acktr_eig_job* jobs, int count, float* e_work, int* info_dev, float thresh,
                                       void* stream);
 
+/* The same decomposition (kfac.py:208-214) for 32 < n <= acktr_jacobi_block_max_n() (2048) by a hand-written BLOCKED
+ * one-sided Jacobi (csrc/jacobi_block.hip): 32-column blocks meet pairwise in round-robin rounds; per round one Gram
+ * launch (fp32 MFMA), one 64 x 64 two-sided Jacobi launch (LDS) and one apply launch (MFMA) serve ALL `count` (<= 64)
+ * matrices of the call.  `jobs` is a HOST array; a (n x n, symmetric, upper triangle authoritative like symeig) is only
+ * read; d[n] ascending and thresholded; qt[n x n] rows = eigenvectors.  Relative rotation criterion: small eigenpairs
+ * keep column-scaled accuracy (a tridiagonalisation-based solver's error is eps*||A|| absolute).  The call synchronises
+ * `stream` once per sweep (convergence counters) and returns with the final launches enqueued on `stream`.
+ * workspace: acktr_sym_eig_jacobi_block_workspace_bytes(ns, count), 256-byte aligned.  sweeps_out (host, nullable)
+ * receives the sweeps each matrix took (negative: not converged within max_sweeps; max_sweeps <= 0 -> 24). */
+typedef struct acktr_jacobi_job { const float* a; float* d; float* qt; int n; } acktr_jacobi_job;
+int acktr_jacobi_block_max_n(void);
+long acktr_sym_eig_jacobi_block_workspace_bytes(const int* ns, int count);
+int acktr_sym_eig_jacobi_block_f32(const acktr_jacobi_job* jobs, int count, float thresh, void* workspace,
+                                   long workspace_bytes, int max_sweeps, int* sweeps_out, void* stream);
+
 /* v = Q_g [ (Q_g^T G Q_a) / (d_g d_a^T + damping) ] Q_a^T -- kfac.py:216-227, G = grad viewed [OUT, IN];
  * tmp1, tmp2: OUT*IN floats each. */
 int acktr_kfac_precondition_f32(const float* grad, const float* qt_g, const float* d_g, const float* qt_a,

@@ -51,6 +51,11 @@ class ConvPackJob(ctypes.Structure):
                 ('C', c_i), ('H', c_i), ('W', c_i), ('OC', c_i), ('KH', c_i), ('KW', c_i), ('S', c_i), ('dgrad', c_i)]
 
 
+class JacobiJob(ctypes.Structure):
+    """struct acktr_jacobi_job (include/acktr_hip.h); also the element of the device descriptor array of the LDS kernel"""
+    _fields_ = [('a', c_p), ('d', c_p), ('qt', c_p), ('n', c_i)]
+
+
 class EigJob(ctypes.Structure):
     """struct acktr_eig_job (include/acktr_hip.h)"""
     _fields_ = [('a_inout_qt', c_p), ('d', c_p), ('n', c_i), ('reserved', c_i)]
@@ -103,6 +108,9 @@ _PROTOS = {
     'acktr_kfac_running_stat_f32': (c_i, [c_p, c_p, c_l, c_f, c_f, c_i, c_p]),
     'acktr_jacobi_max_n': (c_i, []),
     'acktr_sym_eig_jacobi_batched_f32': (c_i, [c_p, c_i, c_i, c_f, c_p]),
+    'acktr_jacobi_block_max_n': (c_i, []),
+    'acktr_sym_eig_jacobi_block_workspace_bytes': (c_l, [ctypes.POINTER(c_i), c_i]),
+    'acktr_sym_eig_jacobi_block_f32': (c_i, [ctypes.POINTER(JacobiJob), c_i, c_f, c_p, c_l, c_i, ctypes.POINTER(c_i), c_p]),
     'acktr_sym_eig_rocsolver_f32': (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p]),
     'acktr_sym_eig_rocsolver_multi_f32': (c_i, [ctypes.POINTER(EigJob), c_i, c_p, c_p, c_f, c_p]),
     'acktr_kfac_precondition_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),

@@ -11,6 +11,7 @@ running-average twins) -- one RCCL all-reduce each under data parallelism; eigen
 ROWS (`qt = Q^T`), eigenvalues ascending.
 """
 import ctypes
+import os
 
 import torch
 import torch.nn as nn
@@ -33,8 +34,7 @@ class SplitBias(nn.Module):
         self.module.bias = None
 
 
-class _JacobiDesc(ctypes.Structure):
-    _fields_ = [('a', ctypes.c_void_p), ('d', ctypes.c_void_p), ('qt', ctypes.c_void_p), ('n', ctypes.c_int)]
+_JacobiDesc = _hip.JacobiJob          # {a, d, qt, n}: device descriptor of the LDS kernel, host job of the blocked one
 
 
 class _Mod(object):
@@ -173,14 +173,20 @@ class KFACOptimizer(optim.Optimizer):
         # eigendecomposition work list: (run bucket, qt bucket, d bucket, offset, d offset, n), one per factor,
         # sharded layer-wise over the data-parallel ranks (greedy by n^3) -- SURVEY 8(e)
         L = _hip.lib()
-        jmax = L.acktr_jacobi_max_n()
+        jmax = L.acktr_jacobi_max_n()                     # LDS-resident batched Jacobi (one workgroup per factor)
+        # blocked one-sided Jacobi above that (csrc/jacobi_block.hip) up to ACKTR_EIG_BLOCK_MAX_N (default 1024: north_star's
+        # "hand-written batched Jacobi for factors of 1024 or less"), rocSOLVER syevd beyond -- NatureCNN's 1568 factor, whose
+        # solve then runs CONCURRENTLY with the Jacobi launches.  ACKTR_EIG_BLOCK_MAX_N=2048 sends the 1568 factor through
+        # the Jacobi too: the update lands 5x closer to fp64 (3.8e-4 against 2.0e-3 for the reference's own fp32 run) at
+        # 66 ms per eigen step instead of ~33; =0 restores the round-1 path (rocSOLVER for everything above 128).
+        bmax = min(int(os.environ.get('ACKTR_EIG_BLOCK_MAX_N', '1024')), L.acktr_jacobi_block_max_n())
         work = []
         for m in self._mods:
             work.append((self.aa_run, self.qt_a, self.d_a_flat, m.oa, m.da_off, m.na))
             work.append((self.gg_run, self.qt_g, self.d_g_flat, m.og, m.dg_off, m.ng))
         self._eig_work = work
         self._eig_owner = assign_eig_owners([w[5] for w in work], self.dp.world)
-        descs, self._big = [], []
+        descs, self._big, self._blk = [], [], []
         self._jac_max = 1
         for w, own in zip(work, self._eig_owner):
             if own != self.dp.rank:
@@ -189,8 +195,20 @@ class KFACOptimizer(optim.Optimizer):
             if n <= jmax:       # batched Jacobi descriptors (built once: pointers are stable)
                 descs.append(_JacobiDesc(run.data_ptr() + 4 * off, dfl.data_ptr() + 4 * doff, qt.data_ptr() + 4 * off, n))
                 self._jac_max = max(self._jac_max, n)
+            elif n <= bmax:
+                self._blk.append(w)
             else:
                 self._big.append(w)
+        if self._blk:              # host job table + workspace of the blocked Jacobi (pointers are stable)
+            self._blk_jobs = (_hip.JacobiJob * len(self._blk))(*[
+                _hip.JacobiJob(run.data_ptr() + 4 * off, dfl.data_ptr() + 4 * doff, qt.data_ptr() + 4 * off, n)
+                for run, qt, dfl, off, doff, n in self._blk])
+            ns = (ctypes.c_int * len(self._blk))(*[w[5] for w in self._blk])
+            nbytes = L.acktr_sym_eig_jacobi_block_workspace_bytes(ns, len(self._blk))
+            if nbytes < 0:
+                raise RuntimeError('acktr_sym_eig_jacobi_block_workspace_bytes rejected the factor sizes')
+            self._blk_ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dev)
+            self._blk_sweeps = (ctypes.c_int * len(self._blk))()
         if self._big:              # host-side job table for the concurrent rocSOLVER solves (pointers are stable)
             self.e_work = z(sum(w[5] for w in self._big))
             self.info = torch.zeros(len(self._big), dtype=torch.int32, device=dev)
@@ -321,12 +339,32 @@ class KFACOptimizer(optim.Optimizer):
             rc = L.acktr_sym_eig_jacobi_batched_f32(_hip.dev_ptr(self._jac_descs, torch.uint8), self._jac_count,
                                                     self._jac_max, 1e-6, stream)
             _hip.check(rc, 'acktr_sym_eig_jacobi_batched_f32')
+        big_thread, big_err = None, []
         if self._big:
             for run, qt, dfl, off, doff, n in self._big:        # syevd works in place: running average -> Q^T slot
                 qt[off:off + n * n].copy_(run[off:off + n * n])
-            rc = L.acktr_sym_eig_rocsolver_multi_f32(self._big_jobs, len(self._big), _hip.dev_ptr(self.e_work),
-                                                     _hip.dev_ptr(self.info, torch.int32), 1e-6, stream)
-            _hip.check(rc, 'acktr_sym_eig_rocsolver_multi_f32')
+
+            def solve_big():
+                # side streams that fork from `stream` at this point; returns after they have drained (host join)
+                torch.cuda.set_device(dev)                      # a new host thread starts on device 0
+                rc = L.acktr_sym_eig_rocsolver_multi_f32(self._big_jobs, len(self._big), _hip.dev_ptr(self.e_work),
+                                                         _hip.dev_ptr(self.info, torch.int32), 1e-6, stream)
+                if rc != 0:
+                    big_err.append((rc, L.acktr_last_error().decode('utf-8', 'replace')))
+            if self._blk:      # overlap the host-driven rocSOLVER chain with the Jacobi launches (ctypes drops the GIL)
+                import threading
+                big_thread = threading.Thread(target=solve_big)
+                big_thread.start()
+            else:
+                solve_big()
+        if self._blk:
+            rc = L.acktr_sym_eig_jacobi_block_f32(self._blk_jobs, len(self._blk), 1e-6, _hip.dev_ptr(self._blk_ws),
+                                                  self._blk_ws.numel(), 0, self._blk_sweeps, stream)
+            if big_thread is not None:
+                big_thread.join()
+            _hip.check(rc, 'acktr_sym_eig_jacobi_block_f32')
+        if big_err:
+            raise RuntimeError('acktr_sym_eig_rocsolver_multi_f32 failed (rc=%d): %s' % big_err[0])
         if self.dp.active:
             # every factor was decomposed by exactly one rank: zero the slots this rank does not own and SUM
             # all-reduce the four flat buckets (= a broadcast from each owner in one collective per bucket)

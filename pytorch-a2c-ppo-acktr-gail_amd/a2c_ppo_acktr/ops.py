@@ -10,6 +10,7 @@ from . import _hip
 
 f32 = torch.float32
 _ws_cache = {}
+WS_MIN_BYTES = 1 << 20
 _ws_retired = []          # outgrown buffers, kept alive for captured graphs that still point into them
 
 # Optional per-launch timing with HIP events on the launch stream (used by bench.py for the roofline
@@ -62,7 +63,7 @@ def workspace(device, nbytes, tag='ws'):
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
             _ws_retired.append(buf)
-        want = max(int(nbytes), 1 << 20, 2 * buf.numel() if buf is not None else 0)
+        want = max(int(nbytes), WS_MIN_BYTES, 2 * buf.numel() if buf is not None else 0)
         buf = torch.empty(want, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf

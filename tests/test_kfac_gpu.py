@@ -112,7 +112,78 @@ def test_jacobi_batched(sizes):
         assert np.linalg.norm(recon - A) <= 5e-5 * np.linalg.norm(A) + 2e-6 * n
 
 
-@pytest.mark.parametrize('n', [256, 576, 1568])
+def _block_jacobi(mats, max_sweeps=0, thresh=1e-6):
+    from a2c_ppo_acktr import _hip
+    L = _hip.lib()
+    ns = [m.shape[0] for m in mats]
+    ds = [torch.full((n,), float('nan'), device='cuda') for n in ns]
+    qts = [torch.full((n, n), float('nan'), device='cuda') for n in ns]
+    jobs = (_hip.JacobiJob * len(ns))(*[_hip.JacobiJob(m.data_ptr(), d.data_ptr(), q.data_ptr(), n)
+                                         for m, d, q, n in zip(mats, ds, qts, ns)])
+    cns = (ctypes.c_int * len(ns))(*ns)
+    nbytes = L.acktr_sym_eig_jacobi_block_workspace_bytes(cns, len(ns))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device='cuda')
+    sweeps = (ctypes.c_int * len(ns))()
+    rc = L.acktr_sym_eig_jacobi_block_f32(jobs, len(ns), thresh, _hip.dev_ptr(ws), ws.numel(), max_sweeps, sweeps,
+                                          _hip.cur_stream())
+    _hip.check(rc, 'jacobi_block')
+    torch.cuda.synchronize()
+    return ds, qts, list(sweeps)
+
+
+@pytest.mark.parametrize('sizes', [[256, 512, 576, 1024], [129, 200, 33, 64], [1568], [2048, 1000]])
+def test_jacobi_block(sizes):
+    """Blocked one-sided Jacobi (csrc/jacobi_block.hip) for 32 < n <= 2048, several factors per call: eigenvalues
+    ascending and thresholded, Q Lambda Q^T reconstructs the input, rows orthonormal (never compare Q itself).
+    Mix of full-rank and rank-deficient PSD inputs (the KFAC factors are both)."""
+    g = torch.Generator().manual_seed(sum(sizes))
+    mats = [_psd(n, max(1, n // 3) if i % 2 == 0 else n + 3, g).cuda() for i, n in enumerate(sizes)]
+    keep = [m.clone() for m in mats]
+    ds, qts, sweeps = _block_jacobi(mats, max_sweeps=48)
+    print('sizes', sizes, 'sweeps', sweeps)
+    # (random rank-deficient inputs converge slowly: 1568 columns in a 522-dimensional range take ~30 sweeps)
+    assert all(0 < s_ <= 48 for s_ in sweeps), sweeps
+    for m, k_, d, q, n in zip(mats, keep, ds, qts, sizes):
+        assert torch.equal(m, k_), 'the input factor must not be modified'
+        A = m.cpu().double().numpy()
+        w = np.linalg.eigvalsh(A)
+        dd = d.cpu().double().numpy()
+        Q = q.cpu().double().numpy().T
+        assert np.isfinite(dd).all() and np.isfinite(Q).all()
+        assert np.all(np.diff(dd) >= 0), 'ascending'
+        w_thr = np.where(w > 1e-6, w, 0.0)
+        assert np.abs(dd - w_thr).max() <= 2e-5 * max(w.max(), 1.0) + 2e-6
+        assert np.abs(Q.T @ Q - np.eye(n)).max() < 5e-5
+        recon = Q @ np.diag(dd) @ Q.T
+        assert np.linalg.norm(recon - A) <= 2e-5 * np.linalg.norm(A) + 2e-6 * n
+
+
+def test_jacobi_block_relative_accuracy_of_small_eigenvalues():
+    """The property the KFAC update needs: on a GRADED positive definite matrix A = D C D (C well
+    conditioned, D spanning 2.5 decades) one-sided Jacobi with a relative rotation criterion gets every eigenvalue to a
+    small RELATIVE error (Demmel-Veselic), where a tridiagonalisation-based fp32 solver is only accurate to
+    eps * lambda_max in absolute terms and loses the small ones."""
+    n = 384
+    g = torch.Generator().manual_seed(5)
+    X = torch.randn(n, 2 * n, generator=g, dtype=torch.float64)
+    C = X @ X.t() / (2 * n)
+    dC = C.diagonal().rsqrt()
+    C = C * dC[:, None] * dC[None, :]
+    D = torch.logspace(0, -2.5, n, dtype=torch.float64)[torch.randperm(n, generator=g)]
+    A = (C * D[:, None] * D[None, :]).float().cuda()
+    (d,), (q,), sweeps = _block_jacobi([A], thresh=0.0)
+    w = torch.linalg.eigvalsh(A.cpu().double())
+    assert float(w.min()) > 0
+    rel_mine = float(((d.cpu().double() - w).abs() / w).max())
+    w32 = torch.linalg.eigvalsh(A.cpu())
+    rel_lap = float(((w32.double() - w).abs() / w).max())
+    print('sweeps', sweeps, 'max relative eigenvalue error: blocked Jacobi %.2e, LAPACK fp32 %.2e; lambda range %.1e .. %.1e'
+          % (rel_mine, rel_lap, float(w.min()), float(w.max())))
+    assert rel_mine < 1e-4 and rel_mine < rel_lap
+
+
+@pytest.mark.parametrize('n', [256, 576, 1568, 3137])      # 3137 = 64*7*7+1: the OpenAI-baselines FC factor north_star names
 def test_rocsolver_eig(n):
     from a2c_ppo_acktr import _hip
     g = torch.Generator().manual_seed(n)
@@ -156,7 +227,12 @@ def test_precondition_vs_torch(OUT, IN):
 def test_acktr_update_vs_reference(ci):
     """Full A2C_ACKTR(acktr=True).update x3 (eigendecompositions at steps 0 and 2).  Losses, factors and
     parameters against the reference goldens; the preconditioned update against the fp64 truth with the
-    reference's own fp32 error as yardstick (see tests/test_oracle_kfac.py for why)."""
+    reference's own fp32 error as yardstick (see tests/test_oracle_kfac.py for why): the HIP path must be at least as
+    close to fp64 as the reference's fp32 CPU run is (k = 1, + the north_star 1e-3).  Round 1 needed k = 4: the error
+    sat in the eigensolver stage (tools/kfac_stage_err.py; rocSOLVER ssyevd 3.5e-3 against LAPACK's 1.6e-3 on the same
+    factors); the blocked one-sided Jacobi (csrc/jacobi_block.hip) brings that stage to 4e-5..9e-5.  Measured
+    e_mine / e_ref: 1.0e-3 / 2.1e-3, 9.1e-4 / 1.9e-3, 2.7e-3 / 6.8e-3 (1568 factor on rocSOLVER, the default);
+    4.6e-4, 1.1e-4, 2.5e-3 with ACKTR_EIG_BLOCK_MAX_N=2048 (every factor on the Jacobi)."""
     from a2c_ppo_acktr import algo
     from test_oracle_kfac import fp64_truth
     tag, kind, od, A, T, N = KFAC_CASES[ci]
@@ -193,14 +269,14 @@ def test_acktr_update_vs_reference(ci):
                                               lambda n: params[n].grad.detach().cpu().numpy(),
                                               lambda n: truth[it][unsplit_name(n)])
             print('    %-36s ref %.2e mine %.2e norm %.3g' % (n, r1, r2, float(G[tag + '/update%d/kfgrad/%s#norm' % (it, n)])))
-        assert e_mine <= 4.0 * e_ref + 1e-3, (it, e_ref, e_mine, e_mg)
+        assert e_mine <= 1.0 * e_ref + 1e-3, (it, e_ref, e_mine, e_mg)
         if kind == 'mlp':      # every factor full rank here: the direct north-star bar holds
             assert e_mg <= 1e-3, (it, e_mg)
         p_ref, p_mine, p_mg = update_vector_errors(G, tag + '/update%d/param/' % it + '%s', names,
                                                    lambda n: params[n].detach().cpu().numpy(),
                                                    lambda n: truth[it]['param:' + unsplit_name(n)])
         print(tag, 'update', it, 'params: e_ref %.3g e_mine %.3g mine-vs-golden %.3g' % (p_ref, p_mine, p_mg))
-        assert p_mine <= 4.0 * p_ref + 1e-4 and p_mg <= 1e-3, (it, p_ref, p_mine, p_mg)
+        assert p_mine <= 1.0 * p_ref + 1e-4 and p_mg <= 1e-3, (it, p_ref, p_mine, p_mg)
 
 
 @pytest.mark.parametrize('ci', range(len(KFAC_CASES)))

@@ -359,7 +359,8 @@ def test_captured_graph_survives_workspace_growth():
               eps=1e-5, max_grad_norm=0.5)
 
     def run(use_graph, grow):
-        ops._ws_cache.clear()                       # start from empty caches so that B's shapes really outgrow A's
+        ops._ws_cache.clear()                       # start from empty caches (and no 1 MB floor) so that B's shapes
+        ops.WS_MIN_BYTES = 4096                     # really outgrow A's
         pol = make_policy('cnn', None, 6, 77)
         ro = synth.make_rollouts(8, 4, (4, 84, 84), 'discrete', 6, salt=1700)
         rs = make_storage(ro, (4, 84, 84), Discrete(6))
@@ -387,7 +388,11 @@ def test_captured_graph_survives_workspace_growth():
             out.append(agent.update(rs))
         return out, pol.flat_params.clone()
 
-    l_eager, p_eager = run(False, False)
-    l_graph, p_graph = run(True, True)
+    try:
+        l_eager, p_eager = run(False, False)
+        l_graph, p_graph = run(True, True)
+    finally:
+        ops.WS_MIN_BYTES = 1 << 20
+        ops._ws_cache.clear()
     assert l_eager == l_graph
     assert torch.equal(p_eager, p_graph)

@@ -169,6 +169,13 @@ def side_metrics(device):
     opt.step = timed_step
     _timed_updates(agent, rs, 21, 540)                      # optimizer steps 23..43: eig at 30 and 40
     opt.step = inner
+    # one more update launch by launch with HIP events around the KFAC GEMM-class operators (factor SYRKs on the
+    # symmetric-half flop count R*D*(D+1) of SURVEY 8(d), preconditioner GEMMs 4*OUT*IN*(OUT+IN))
+    from a2c_ppo_acktr import ops
+    ops.profiler = {}
+    _timed_updates(agent, rs, 1, 570)
+    kprof = {k: v for k, v in ops.profile_summary().items() if k.startswith('kfac_')}
+    ops.profiler = None
     agent.use_graph = True
     eig = [m for is_eig, m in step_ms if is_eig]
     plain = [m for is_eig, m in step_ms if not is_eig]
@@ -178,6 +185,18 @@ def side_metrics(device):
                                samples_per_s=round(T * N * len(ms) / (sum(ms) * 1e-3), 1),
                                kfac_step_ms=dict(with_eig=round(statistics.median(eig), 3) if eig else None,
                                                  without_eig=round(statistics.median(plain), 3), n_eig=len(eig)))
+    if kprof:
+        fac = {k: v for k, v in kprof.items() if k.startswith('kfac_cov_a_conv')}
+        dom = max(fac.items(), key=lambda kv: kv[1]['total_ms'])
+        ach = dom[1]['flops_per_call'] / (dom[1]['avg_ms'] * 1e-3) / 1e12
+        out['roofline_kfac'] = dict(bound='mfma', kernel=dom[0], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
+                                    unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                                    avg_launch_ms=round(dom[1]['avg_ms'], 4), flop_per_launch=dom[1]['flops_per_call'],
+                                    flop_count='symmetric half R*D*(D+1) (SURVEY 8(d)); the kernel computes the upper '
+                                               'triangle of 128x128 tiles and mirrors it',
+                                    operators={k: dict(calls=v['calls'], avg_ms=round(v['avg_ms'], 4),
+                                                       tflops=round(v['flops_per_call'] / (v['avg_ms'] * 1e-3) / 1e12, 2))
+                                               for k, v in sorted(kprof.items(), key=lambda kv: -kv[1]['total_ms'])})
     # ---- configs[2] at the top of its range on ONE GPU: 256 processes x 128 steps, 4 epochs x 4 minibatches of 8192
     # (the headline line keeps 32 processes per GPU so that 8 GPUs land on this global size)
     T, N = T_STEPS, 256
@@ -430,6 +449,8 @@ def main():
         if world == 1 and not args.no_side_metrics:
             try:
                 out['side_metrics'] = side_metrics(device)
+                if 'roofline_kfac' in out['side_metrics']:
+                    out['roofline_kfac'] = out['side_metrics'].pop('roofline_kfac')
             except Exception as e:                       # never lose the headline line over a side figure
                 out['side_metrics'] = dict(error=repr(e))
         if world == 1 and not args.no_cpu_baseline:

@@ -107,6 +107,7 @@ class KFACOptimizer(optim.Optimizer):
         self._ready_device = None
         self.dp = DataParallel()          # replaced by A2C_ACKTR with its own context
         self._ext_noise = None
+        self._side_stream = None
 
     # ------------------------------------------------------------------ module discovery (kfac.py:179-188)
     def _prepare_model(self):
@@ -225,8 +226,9 @@ class KFACOptimizer(optim.Optimizer):
     def _cov_dense(self, a2d, ptr, ld, B, D, alpha, out):
         L = _hip.lib()
         ws = ops.workspace(out.device, L.acktr_kfac_cov_workspace_bytes(D, B), 'kfac')
-        rc = L.acktr_kfac_cov_dense_f32(ptr, ld, B, D, float(alpha), _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(),
-                                        _hip.cur_stream(out.device))
+        with ops._Timed('kfac_cov_dense%d' % D, float(B) * D * (D + 1)):
+            rc = L.acktr_kfac_cov_dense_f32(ptr, ld, B, D, float(alpha), _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(),
+                                            _hip.cur_stream(out.device))
         _hip.check(rc, 'acktr_kfac_cov_dense_f32')
 
     def accumulate_stats(self, acts, actions, gather_idx, inv_batch, dp):
@@ -263,8 +265,10 @@ class KFACOptimizer(optim.Optimizer):
                 OH, OW = (H - KH) // stride + 1, (W - KW) // stride + 1
                 alpha = (sc * sc) / (float(Bg) * float(OH * OW) ** 2)
                 ws = ops.workspace(dev, L.acktr_kfac_cov_workspace_bytes(C * KH * KW, B * OH * OW), 'kfac')
-                rc = L.acktr_kfac_cov_a_conv_f32(_hip.dev_ptr(x), _hip.dev_ptr(idx, torch.int64), B, C, H, W, KH, KW,
-                                                 stride, alpha, _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(), stream)
+                D_, R_ = C * KH * KW, B * OH * OW           # symmetric-half flop count R D (D+1), SURVEY 8(d)
+                with ops._Timed('kfac_cov_a_conv%ds%d' % (KH, stride), float(R_) * D_ * (D_ + 1)):
+                    rc = L.acktr_kfac_cov_a_conv_f32(_hip.dev_ptr(x), _hip.dev_ptr(idx, torch.int64), B, C, H, W, KH, KW,
+                                                     stride, alpha, _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(), stream)
                 _hip.check(rc, 'acktr_kfac_cov_a_conv_f32')
             else:
                 a = lin_in[m.layer]
@@ -335,9 +339,17 @@ class KFACOptimizer(optim.Optimizer):
         L = _hip.lib()
         dev = self.aa_run.device
         stream = _hip.cur_stream(dev)
+        side = None
         if self._jac_count:
+            # the LDS-resident solver (one workgroup per small factor, ~2 ms of a handful of CUs) on a side stream, so that
+            # neither the rocSOLVER fork point nor the blocked Jacobi's launches queue behind it
+            cur = torch.cuda.current_stream(dev)
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
+            side.wait_stream(cur)
             rc = L.acktr_sym_eig_jacobi_batched_f32(_hip.dev_ptr(self._jac_descs, torch.uint8), self._jac_count,
-                                                    self._jac_max, 1e-6, stream)
+                                                    self._jac_max, 1e-6, ctypes.c_void_p(side.cuda_stream))
             _hip.check(rc, 'acktr_sym_eig_jacobi_batched_f32')
         big_thread, big_err = None, []
         if self._big:
@@ -365,6 +377,8 @@ class KFACOptimizer(optim.Optimizer):
             _hip.check(rc, 'acktr_sym_eig_jacobi_block_f32')
         if big_err:
             raise RuntimeError('acktr_sym_eig_rocsolver_multi_f32 failed (rc=%d): %s' % big_err[0])
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
         if self.dp.active:
             # every factor was decomposed by exactly one rank: zero the slots this rank does not own and SUM
             # all-reduce the four flat buckets (= a broadcast from each owner in one collective per bucket)
@@ -392,12 +406,13 @@ class KFACOptimizer(optim.Optimizer):
             for m in self._mods:
                 g = pol.grad_view(m.param, gflat)
                 v = pol.grad_view(m.param, self.v_flat)
-                rc = L.acktr_kfac_precondition_f32(
-                    _hip.dev_ptr(g), ctypes.c_void_p(self.qt_g.data_ptr() + 4 * m.og),
-                    ctypes.c_void_p(self.d_g_flat.data_ptr() + 4 * m.dg_off),
-                    ctypes.c_void_p(self.qt_a.data_ptr() + 4 * m.oa),
-                    ctypes.c_void_p(self.d_a_flat.data_ptr() + 4 * m.da_off), m.ng, m.na, float(la),
-                    _hip.dev_ptr(self.tmp1), _hip.dev_ptr(self.tmp2), _hip.dev_ptr(v), stream)
+                with ops._Timed('kfac_precondition_%dx%d' % (m.ng, m.na), 4.0 * m.ng * m.na * (m.ng + m.na)):
+                    rc = L.acktr_kfac_precondition_f32(
+                        _hip.dev_ptr(g), ctypes.c_void_p(self.qt_g.data_ptr() + 4 * m.og),
+                        ctypes.c_void_p(self.d_g_flat.data_ptr() + 4 * m.dg_off),
+                        ctypes.c_void_p(self.qt_a.data_ptr() + 4 * m.oa),
+                        ctypes.c_void_p(self.d_a_flat.data_ptr() + 4 * m.da_off), m.ng, m.na, float(la),
+                        _hip.dev_ptr(self.tmp1), _hip.dev_ptr(self.tmp2), _hip.dev_ptr(v), stream)
                 _hip.check(rc, 'acktr_kfac_precondition_f32')
             ws = ops.workspace(dev, L.acktr_optim_workspace_bytes(), 'optim')
             rc = L.acktr_kfac_kl_clip_f32(_hip.dev_ptr(self.v_flat), _hip.dev_ptr(gflat), flat.numel(), float(self.lr),

@@ -17,6 +17,7 @@
 // Plain operators are used on purpose: the __f*_rn() header wrappers are compiled under the
 // header's own contraction mode and DO fuse into v_fma after inlining.
 #include <mutex>
+#include <type_traits>
 
 #include "common.hpp"
 #include "../../include/acktr_hip.h"
@@ -27,8 +28,9 @@ namespace acktr {
 
 constexpr int SCAN_TE = 32;   // environments per workgroup
 constexpr int SCAN_TC = 64;   // time steps per chunk
-constexpr int SCAN_THREADS = 256;
-constexpr int SCAN_EPT = SCAN_TE * SCAN_TC / SCAN_THREADS;   // elements per thread per chunk (8)
+constexpr int SCAN_LOADERS = 256;                            // waves 1..4: HBM loads, staging, result write-back
+constexpr int SCAN_THREADS = 64 + SCAN_LOADERS;              // wave 0: the dependent chain, nothing else
+constexpr int SCAN_EPT = SCAN_TE * SCAN_TC / SCAN_LOADERS;   // elements per loader thread per chunk (8)
 constexpr int SCAN_PITCH = SCAN_TC + 4;                      // LDS row (one environment's chunk) pitch, 16-byte multiple
 typedef float scan_f4 __attribute__((ext_vector_type(4)));
 
@@ -41,12 +43,20 @@ struct ScanCfg {
 };
 
 // Roles inside a workgroup, per 64-step chunk c (all overlapped, one barrier per chunk):
-//   all 4 waves : request chunk c+1 from HBM into registers (branch-free, 40 loads in flight per thread)
-//   wave 0      : the dependent chain of chunk c, operands and results through LDS as 16-byte vectors laid out
-//                 time-contiguous per environment (one ds_read_b128 = 4 steps of one operand)
-//   waves 1..3  : stream the results of chunk c-1 from LDS to HBM (coalesced 128-byte rows)
-//   all 4 waves : pre-compute chunk c+1's carry-independent terms into the other LDS buffer
-template <bool GAE, bool PROPER>
+//   wave 0      : ONLY the dependent chain of chunk c (raised priority), operands and results through LDS as 16-byte
+//                 vectors laid out time-contiguous per environment (one ds_read_b128 = 4 steps of one operand), fetched
+//                 two groups ahead of their use
+//   waves 1..4  : request chunk c+3 from HBM into registers (branch-free; THREE chunks = 120 loads per thread in flight, so
+//                 a load has two full chunk periods to land before it is staged), write the results of chunk c-1 to HBM (coalesced 128-byte
+//                 rows, straight-line predicated stores), pre-compute chunk c+1's carry-independent terms into the other
+//                 LDS buffer
+// (Round 1 had wave 0 share the load / staging duty and a run-time write-back loop whose back edge drained the
+// prefetch: 31 ns per step at T = 2048 x N = 1024; the chain alone is ~10 ns.)
+// VEC = 4 (N % 4 == 0, 16-byte aligned arrays): a loader thread's 8 elements per chunk are two quads of adjacent
+// environments, one 16-byte load per array and quad -- 10 loads per chunk instead of 40, so three chunks of prefetch fit
+// under the 64 outstanding vector-memory operations a wave can have (with 40 per chunk the issue itself stalled and the
+// loaders, not the chain, set the pace: 52 us against 28 us for the chain alone at T = 2048).  VEC = 1: any N.
+template <bool GAE, bool PROPER, int VEC>
 __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
     const float* rewards, float* value_preds, float* returns, const float* masks, const float* bad_masks,
     const float* next_value, int T, int N, float g, float gl) {
@@ -59,6 +69,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
     auto out_at = [&](int buf, int le) { return lout + (buf * SCAN_TE + le) * SCAN_PITCH; };
 
     const int tid = threadIdx.x;
+    const int lt = tid - 64;                        // loader thread index (>= 0 for waves 1..4)
     const int e0 = blockIdx.x * SCAN_TE;
     const int nchunks = (T + SCAN_TC - 1) / SCAN_TC;
 
@@ -69,122 +80,196 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
         else returns[(long)T * N + e0 + tid] = nv;
     }
 
-    float st[SCAN_EPT][5];
+    float st[3][SCAN_EPT][5];                       // three chunks of loads in flight (set = chunk % 3)
+    // element i of this loader thread -> (time row j of the chunk, local environment le)
+    auto el_j = [&](int i) { return VEC == 4 ? (lt + SCAN_LOADERS * (i >> 2)) / (SCAN_TE / 4) : (lt + SCAN_LOADERS * i) / SCAN_TE; };
+    auto el_le = [&](int i) {
+        return VEC == 4 ? ((lt + SCAN_LOADERS * (i >> 2)) % (SCAN_TE / 4)) * 4 + (i & 3) : (lt + SCAN_LOADERS * i) % SCAN_TE;
+    };
 
-    // branch-free: out-of-range (t < 0 on the last chunk, n >= N on the last workgroup) elements are fetched from a
-    // clamped, valid address and never stored, so the loads of a chunk are issued back to back and stay in flight
-    // during the serial scan
-    auto issue_loads = [&](int c) {
-        const int tlo = T - (c + 1) * SCAN_TC;
+    // branch-free: out-of-range (t < 0 on the last chunk, n >= N on the last workgroup, chunks past the end) elements are
+    // fetched from a clamped, valid address and never stored, so the loads of a chunk are issued back to back
+    auto issue_loads = [&](auto P, int c) {
+        constexpr int p = decltype(P)::value;
+        const int cc = c < nchunks ? c : nchunks - 1;
+        const int tlo = T - (cc + 1) * SCAN_TC;
+        if constexpr (VEC == 4) {
 #pragma unroll
-        for (int i = 0; i < SCAN_EPT; ++i) {
-            const int e = tid + SCAN_THREADS * i;
-            const int j = e / SCAN_TE, le = e % SCAN_TE;
-            const int t = (tlo + j) < 0 ? 0 : tlo + j;
-            const int n = (e0 + le) < N ? e0 + le : N - 1;
-            const long o = (long)t * N + n;
-            st[i][0] = rewards[o];
-            st[i][1] = masks[o + N];                                  // masks[t+1]
-            if (GAE || PROPER) st[i][2] = value_preds[o];             // V[t]
-            if (GAE) st[i][3] = value_preds[o + N];                   // V[t+1]  (t = T-1 is patched below)
-            if (PROPER) st[i][4] = bad_masks[o + N];                  // bad_masks[t+1]
+            for (int u = 0; u < SCAN_EPT / 4; ++u) {
+                const int j = el_j(4 * u), le = el_le(4 * u);
+                const int t = (tlo + j) < 0 ? 0 : tlo + j;
+                const int n = (e0 + le) < N ? e0 + le : N - 4;           // N % 4 == 0: a quad is wholly in or out
+                const long o = (long)t * N + n;
+                auto put = [&](int k, const float* base) {
+                    const scan_f4 q = *reinterpret_cast<const scan_f4*>(base);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) st[p][4 * u + v][k] = q[v];
+                };
+                put(0, rewards + o);
+                put(1, masks + o + N);
+                if (GAE || PROPER) put(2, value_preds + o);
+                if (GAE) put(3, value_preds + o + N);
+                if (PROPER) put(4, bad_masks + o + N);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SCAN_EPT; ++i) {
+                const int j = el_j(i), le = el_le(i);
+                const int t = (tlo + j) < 0 ? 0 : tlo + j;
+                const int n = (e0 + le) < N ? e0 + le : N - 1;
+                const long o = (long)t * N + n;
+                st[p][i][0] = rewards[o];
+                st[p][i][1] = masks[o + N];                                  // masks[t+1]
+                if (GAE || PROPER) st[p][i][2] = value_preds[o];             // V[t]
+                if (GAE) st[p][i][3] = value_preds[o + N];                   // V[t+1]  (t = T-1 is patched for chunk 0)
+                if (PROPER) st[p][i][4] = bad_masks[o + N];                  // bad_masks[t+1]
+            }
         }
     };
-    auto stage_to_lds = [&](int buf) {
+    auto stage_to_lds = [&](auto P, int buf) {
+        constexpr int p = decltype(P)::value;
 #pragma unroll
         for (int i = 0; i < SCAN_EPT; ++i) {
-            const int e = tid + SCAN_THREADS * i;
-            const int j = e / SCAN_TE, le = e % SCAN_TE;
-            const float r = st[i][0], m = st[i][1];
+            const int j = el_j(i), le = el_le(i);
+            const float r = st[p][i][0], m = st[p][i][1];
             if (GAE) {
                 // delta = (r + (g*V[t+1])*m) - V[t]          storage.py:77-79 / 95-97
-                const float delta = ((((r) + (((((g) * (st[i][3]))) * (m))))) - (st[i][2]));
+                const float delta = ((((r) + (((((g) * (st[p][i][3]))) * (m))))) - (st[p][i][2]));
                 in_at(buf, 0, le)[j] = delta;
                 in_at(buf, 1, le)[j] = ((gl) * (m));                 // (gamma*lambda)*mask
-                in_at(buf, 2, le)[j] = st[i][2];
-                if (PROPER) in_at(buf, 3, le)[j] = st[i][4];
+                in_at(buf, 2, le)[j] = st[p][i][2];
+                if (PROPER) in_at(buf, 3, le)[j] = st[p][i][4];
             } else {
                 in_at(buf, 0, le)[j] = m;
                 in_at(buf, 1, le)[j] = r;
                 if (PROPER) {
-                    in_at(buf, 2, le)[j] = st[i][4];
-                    in_at(buf, 3, le)[j] = ((((1.0f) - (st[i][4]))) * (st[i][2]));   // (1-b)*V[t]
+                    in_at(buf, 2, le)[j] = st[p][i][4];
+                    in_at(buf, 3, le)[j] = ((((1.0f) - (st[p][i][4]))) * (st[p][i][2]));   // (1-b)*V[t]
                 }
             }
         }
     };
-    // results of chunk c (LDS) -> returns rows; `first`/`step` select the participating threads
-    auto flush = [&](int c, int first, int step) {
+    // results of chunk c (LDS) -> returns rows: a fixed number of predicated stores per loader thread (no loop back edge
+    // for the memory-counter bookkeeping to drain the prefetch at)
+    auto flush = [&](int c) {
         const int buf = c & 1;
         const int tlo = T - (c + 1) * SCAN_TC;
-        for (int e = first; e < SCAN_TE * SCAN_TC; e += step) {
-            const int j = e / SCAN_TE, le = e % SCAN_TE;
-            if (tlo + j >= 0 && e0 + le < N) returns[(long)(tlo + j) * N + e0 + le] = out_at(buf, le)[j];
-        }
-    };
-
-    issue_loads(0);
-    if (GAE) {      // V[T]: the reference reads next_value there (written above, possibly by another lane: use the source)
+        // GAE: the chain leaves gae[t]; R = gae + V[t] (storage.py:83 / 100) is taken here, off the chain wave.  V[t] sits in
+        // the operand buffer of the same parity, at the very slot this thread overwrites right after (stage_to_lds of
+        // chunk c+2 uses the same element mapping), so the read cannot race with another thread's write.
+        float v[SCAN_EPT];
 #pragma unroll
         for (int i = 0; i < SCAN_EPT; ++i) {
-            const int e = tid + SCAN_THREADS * i;
-            const int j = e / SCAN_TE, le = e % SCAN_TE;
-            const int n = (e0 + le) < N ? e0 + le : N - 1;
-            if (j == SCAN_TC - 1) st[i][3] = next_value[n];
+            const int j = el_j(i), le = el_le(i);
+            v[i] = out_at(buf, le)[j];
+            if (GAE) v[i] = ((v[i]) + (in_at(buf, 2, le)[j]));
         }
+        if constexpr (VEC == 4) {
+#pragma unroll
+            for (int u = 0; u < SCAN_EPT / 4; ++u) {
+                const int j = el_j(4 * u), le = el_le(4 * u);
+                if (tlo + j >= 0 && e0 + le < N)
+                    *reinterpret_cast<scan_f4*>(returns + (long)(tlo + j) * N + e0 + le) =
+                        scan_f4{v[4 * u], v[4 * u + 1], v[4 * u + 2], v[4 * u + 3]};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < SCAN_EPT; ++i) {
+                const int j = el_j(i), le = el_le(i);
+                if (tlo + j >= 0 && e0 + le < N) returns[(long)(tlo + j) * N + e0 + le] = v[i];
+            }
+        }
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+
+    float carry = 0.f;   // gae (GAE) or returns[t+1] (RET): lanes 0..31 of wave 0
+    if (tid >= 64) {
+        issue_loads(P0{}, 0);
+        issue_loads(P1{}, 1);
+        issue_loads(P2{}, 2);
+        if (GAE) {      // V[T]: the reference reads next_value there (written above, possibly by another lane: use the source)
+#pragma unroll
+            for (int i = 0; i < SCAN_EPT; ++i) {
+                const int j = el_j(i), le = el_le(i);
+                const int n = (e0 + le) < N ? e0 + le : N - 1;
+                if (j == SCAN_TC - 1) st[0][i][3] = next_value[n];
+            }
+        }
+        stage_to_lds(P0{}, 0);
+    } else {
+        __builtin_amdgcn_s_setprio(3);
+        if (!GAE && tid < SCAN_TE) carry = next_value[(e0 + tid) < N ? e0 + tid : N - 1];
     }
-    stage_to_lds(0);
     __syncthreads();
 
-    float carry = 0.f;   // gae (GAE) or returns[t+1] (RET)
-    if (!GAE && tid < SCAN_TE) carry = next_value[(e0 + tid) < N ? e0 + tid : N - 1];
-
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        issue_loads(c + 1 < nchunks ? c + 1 : c);     // unconditional (the last chunk is re-requested and dropped)
-
-        if (tid < 64) {
-            if (tid < SCAN_TE) {                      // wave 0, lanes 0..31: the dependent chain
-                const float* p0 = in_at(buf, 0, tid);
-                const float* p1 = in_at(buf, 1, tid);
-                const float* p2 = in_at(buf, NARR > 2 ? 2 : 0, tid);
-                const float* p3 = in_at(buf, NARR > 3 ? 3 : 0, tid);
-                float* po = out_at(buf, tid);
-                scan_f4 a0[2], a1[2], a2[2], a3[2];
-                auto fetch = [&](int set, int j0) {
-                    a0[set] = *reinterpret_cast<const scan_f4*>(p0 + j0);
-                    a1[set] = *reinterpret_cast<const scan_f4*>(p1 + j0);
-                    if (NARR > 2) a2[set] = *reinterpret_cast<const scan_f4*>(p2 + j0);
-                    if (NARR > 3) a3[set] = *reinterpret_cast<const scan_f4*>(p3 + j0);
-                };
-                fetch(0, SCAN_TC - 4);
+    // chain of chunk c by lanes 0..31 of wave 0: operands fetched two 4-step groups ahead
+    auto chain = [&](int buf) {
+        const float* p0 = in_at(buf, 0, tid);
+        const float* p1 = in_at(buf, 1, tid);
+        const float* p2 = in_at(buf, NARR > 2 ? 2 : 0, tid);
+        const float* p3 = in_at(buf, NARR > 3 ? 3 : 0, tid);
+        float* po = out_at(buf, tid);
+        scan_f4 a0[3], a1[3], a2[3], a3[3];
+        auto fetch = [&](int set, int j0) {
+            a0[set] = *reinterpret_cast<const scan_f4*>(p0 + j0);
+            a1[set] = *reinterpret_cast<const scan_f4*>(p1 + j0);
+            if (NARR > 2 && !GAE) a2[set] = *reinterpret_cast<const scan_f4*>(p2 + j0);   // GAE: V[t] is added at write-back
+            if (NARR > 3) a3[set] = *reinterpret_cast<const scan_f4*>(p3 + j0);
+        };
+        constexpr int NG = SCAN_TC / 4;
+        fetch((NG - 1) % 3, 4 * (NG - 1));
+        fetch((NG - 2) % 3, 4 * (NG - 2));
 #pragma unroll
-                for (int q = SCAN_TC / 4 - 1; q >= 0; --q) {
-                    const int set = (SCAN_TC / 4 - 1 - q) & 1;
-                    if (q > 0) fetch(set ^ 1, 4 * (q - 1));          // next 4 steps' operands while this chain runs
-                    scan_f4 res;
+        for (int q = NG - 1; q >= 0; --q) {
+            const int set = q % 3;
+            if (q >= 2) fetch((q - 2) % 3, 4 * (q - 2));
+            // keep the fetch two groups ahead of its use: without the fence the scheduler sinks the ds_reads next to their
+            // consumers and the ~50-cycle LDS latency lands on the dependent chain once per group
+            __builtin_amdgcn_sched_barrier(0);
+            scan_f4 res;
 #pragma unroll
-                    for (int u = 3; u >= 0; --u) {
-                        if (GAE) {
-                            carry = ((a0[set][u]) + (((a1[set][u]) * (carry))));     // gae = delta + (gl*m)*gae
-                            if (PROPER) carry = ((carry) * (a3[set][u]));            // gae *= bad_mask
-                            res[u] = ((carry) + (a2[set][u]));                       // R = gae + V[t]
-                        } else {
-                            carry = ((((((carry) * (g))) * (a0[set][u]))) + (a1[set][u]));   // (R*g)*m + r
-                            if (PROPER) carry = ((((carry) * (a2[set][u]))) + (a3[set][u]));
-                            res[u] = carry;
-                        }
-                    }
-                    *reinterpret_cast<scan_f4*>(po + 4 * q) = res;
+            for (int u = 3; u >= 0; --u) {
+                if (GAE) {
+                    carry = ((a0[set][u]) + (((a1[set][u]) * (carry))));     // gae = delta + (gl*m)*gae
+                    if (PROPER) carry = ((carry) * (a3[set][u]));            // gae *= bad_mask
+                    res[u] = carry;                                          // (R = gae + V[t]: see flush)
+                } else {
+                    carry = ((((((carry) * (g))) * (a0[set][u]))) + (a1[set][u]));   // (R*g)*m + r
+                    if (PROPER) carry = ((((carry) * (a2[set][u]))) + (a3[set][u]));
+                    res[u] = carry;
                 }
             }
-        } else if (c > 0) {
-            flush(c - 1, tid - 64, SCAN_THREADS - 64);               // waves 1..3 write out the previous chunk
+            *reinterpret_cast<scan_f4*>(po + 4 * q) = res;
+            __builtin_amdgcn_sched_barrier(0);
         }
-        stage_to_lds(buf ^ 1);
+    };
+    // loaders at chunk c (set P = c % 3): request chunk c+3 into set P (chunk c's values were staged one chunk ago), write
+    // chunk c-1's results out, stage chunk c+1 (set (c+1) % 3, requested two chunk periods ago) into the other LDS buffer
+    auto loader_step = [&](auto P, int c) {
+        constexpr int p = decltype(P)::value;
+        issue_loads(P, c + 3);
+        if (c > 0) flush(c - 1);
+        stage_to_lds(std::integral_constant<int, (p + 1) % 3>{}, (c + 1) & 1);
+    };
+    auto step = [&](auto P, int c) {
+#if defined(SCAN_DBG_NOLOAD)
+        if (tid >= 64) { }
+#else
+        if (tid >= 64) loader_step(P, c);
+#endif
+#if !defined(SCAN_DBG_NOCHAIN)
+        else if (tid < SCAN_TE) chain(c & 1);
+#endif
         __syncthreads();
+    };
+    for (int c = 0; c < nchunks; c += 3) {
+        step(P0{}, c);
+        if (c + 1 < nchunks) step(P1{}, c + 1);
+        if (c + 2 < nchunks) step(P2{}, c + 2);
     }
-    flush(nchunks - 1, tid, SCAN_THREADS);
+    if (tid >= 64) flush(nchunks - 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -269,24 +354,29 @@ extern "C" int acktr_compute_returns_f32(const float* rewards, float* value_pred
     ACKTR_ARG((long)(T + 1) * N < (1L << 31), "compute_returns: (T+1)*N too large");
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(cdiv(N, SCAN_TE)), block(SCAN_THREADS);
-#define LAUNCH(G, P)                                                                                              \
-    do {                                                                                                          \
-        constexpr int lds_bytes = ScanCfg<G, P>::LDS_BYTES;                                                       \
-        static bool attr_set = false;                                                                             \
-        if (!attr_set && lds_bytes > 48 * 1024) {                                                                 \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(returns_scan_kernel<G, P>),          \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);            \
-            ACKTR_ARG(e == hipSuccess, "compute_returns: hipFuncSetAttribute failed: %s", hipGetErrorString(e));  \
-            attr_set = true;                                                                                      \
-        }                                                                                                         \
-        hipLaunchKernelGGL((returns_scan_kernel<G, P>), grid, block, lds_bytes, s, rewards, value_preds, returns, \
-                           masks, bad_masks, next_value, T, N, gamma32, gamma_lambda32);                          \
+    const uintptr_t al = (uintptr_t)rewards | (uintptr_t)value_preds | (uintptr_t)returns | (uintptr_t)masks |
+                         (uintptr_t)(use_proper_time_limits ? bad_masks : rewards);
+    const bool vec4 = (N % 4 == 0) && (al % 16 == 0);
+#define LAUNCH(G, P, V)                                                                                              \
+    do {                                                                                                             \
+        constexpr int lds_bytes = ScanCfg<G, P>::LDS_BYTES;                                                          \
+        static bool attr_set = false;                                                                                \
+        if (!attr_set && lds_bytes > 48 * 1024) {                                                                    \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(returns_scan_kernel<G, P, V>),          \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);               \
+            ACKTR_ARG(e == hipSuccess, "compute_returns: hipFuncSetAttribute failed: %s", hipGetErrorString(e));     \
+            attr_set = true;                                                                                         \
+        }                                                                                                            \
+        hipLaunchKernelGGL((returns_scan_kernel<G, P, V>), grid, block, lds_bytes, s, rewards, value_preds, returns, \
+                           masks, bad_masks, next_value, T, N, gamma32, gamma_lambda32);                             \
     } while (0)
+#define LAUNCHV(G, P) do { if (vec4) LAUNCH(G, P, 4); else LAUNCH(G, P, 1); } while (0)
     if (use_gae) {
-        if (use_proper_time_limits) LAUNCH(true, true); else LAUNCH(true, false);
+        if (use_proper_time_limits) LAUNCHV(true, true); else LAUNCHV(true, false);
     } else {
-        if (use_proper_time_limits) LAUNCH(false, true); else LAUNCH(false, false);
+        if (use_proper_time_limits) LAUNCHV(false, true); else LAUNCHV(false, false);
     }
+#undef LAUNCHV
 #undef LAUNCH
     ACKTR_LAUNCH_CHECK();
     return 0;

@@ -194,6 +194,13 @@ int acktr_head_step_f32(const acktr_loss_args* args, const float* feat, const fl
 /* dist.log_probs(action) and dist.entropy() per sample -- model.py:74-77 (entropy.mean() is taken by the host). */
 int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions, int B, int A,
                        float* logp, float* entropy, void* stream);
+/* Rollout-side head of Policy.act -- model.py:54-66, distributions.py:22-25,28-29,37-44: the mode (deterministic != 0)
+ * or one sample per row, and dist.log_probs(action) of it.  Categorical: action_out int64[B]; sampling = inverse CDF of
+ * softmax(logits) at the caller's uniform noise[B] in [0,1) (the reference draws with torch.multinomial on its own
+ * generator: same distribution, not the same stream).  DiagGaussian: action_out float[B,A]; sample = mean +
+ * exp(logstd) * noise[B,A] with the caller's standard normal noise (torch.normal's formula). */
+int acktr_dist_act_f32(int dist, const float* dist_in, long ld, const float* logstd, const float* noise,
+                       int deterministic, int B, int A, void* action_out, float* logp, void* stream);
 /* their backward: ddist = dlogp[b]*dlogp/d(dist_in) + dentropy[b]*dentropy/d(dist_in) (either seed nullable);
  * gaussian also returns dlogstd[A] (workspace >= acktr_policy_loss_workspace_bytes(B, A)). */
 int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions,

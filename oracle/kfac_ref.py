@@ -88,15 +88,17 @@ def forward_capture(P, obs, actions):
         x = x.reshape(x.size(0), -1)
         feat = F.relu(lin('base.main.7', x))
         value = lin('base.critic_linear', feat)
-        logits = lin('dist.linear', feat)
-        logp, ent = policy_ref.categorical_logp_entropy(logits, actions)
     else:
-        ha = torch.tanh(lin('base.actor.0', obs))
-        ha = torch.tanh(lin('base.actor.2', ha))
+        feat = torch.tanh(lin('base.actor.0', obs))
+        feat = torch.tanh(lin('base.actor.2', feat))
         hc = torch.tanh(lin('base.critic.0', obs))
         hc = torch.tanh(lin('base.critic.2', hc))
         value = lin('base.critic_linear', hc)
-        mean = lin('dist.fc_mean', ha)
+    if policy_ref.is_categorical(P):            # the head follows the action space, not the base (model.py:30-38)
+        logits = lin('dist.linear', feat)
+        logp, ent = policy_ref.categorical_logp_entropy(logits, actions)
+    else:
+        mean = lin('dist.fc_mean', feat)
         zeros = torch.zeros_like(mean)
         logstd = zeros + P['dist.logstd._bias'].t().view(1, -1)
         caps['dist.logstd'] = (zeros, logstd)
@@ -109,14 +111,20 @@ def forward_capture(P, obs, actions):
 
 def module_list(P):
     """[(module key, kind, param name, layer name)] in the reference's module order."""
-    layers = CNN_LAYERS if policy_ref.is_cnn(P) else MLP_LAYERS
     out = []
-    for name, kind, _ in layers:
+    for name, kind, _ in layer_list(P):
         out.append((name + '#w', kind, name + '.weight', name))
         out.append((name + '#b', 'bias', name + '.bias', name))
-    if not policy_ref.is_cnn(P):
+    if not policy_ref.is_categorical(P):
         out.append(('dist.logstd#b', 'bias', 'dist.logstd._bias', 'dist.logstd'))
     return out
+
+
+def layer_list(P):
+    """Base layers + the head's linear (dist.linear / dist.fc_mean by action space)."""
+    layers = list(CNN_LAYERS if policy_ref.is_cnn(P) else MLP_LAYERS)
+    head = 'dist.linear' if policy_ref.is_categorical(P) else 'dist.fc_mean'
+    return layers[:-1] + [(head, 'linear', None)]
 
 
 def acktr_update(P, st, ro, value_loss_coef, entropy_coef, noise=None):
@@ -129,7 +137,7 @@ def acktr_update(P, st, ro, value_loss_coef, entropy_coef, noise=None):
     act = ro['actions'].reshape(T * N, -1)
     values, logp, ent, caps = forward_capture(P, obs, act)
     mods = module_list(P)
-    layers = CNN_LAYERS if policy_ref.is_cnn(P) else MLP_LAYERS
+    layers = layer_list(P)
     geom = {n: (k, s) for n, k, s in layers}
     do_stats = st['steps'] % st['Ts'] == 0
     if do_stats:                                        # _save_input (kfac.py:144-159)

@@ -59,6 +59,26 @@ def is_cnn(P):
     return 'base.main.0.weight' in P
 
 
+def is_categorical(P):
+    return 'dist.linear.weight' in P
+
+
+def head_param_shapes(hidden, num_actions, categorical):
+    """Parameters of the action head in the reference's order (distributions.py:59-95)."""
+    if categorical:
+        return [('dist.linear.weight', (num_actions, hidden)), ('dist.linear.bias', (num_actions,))]
+    return [('dist.fc_mean.weight', (num_actions, hidden)), ('dist.fc_mean.bias', (num_actions,)),
+            ('dist.logstd._bias', (num_actions, 1))]
+
+
+def with_head(shapes, hidden, num_actions, categorical):
+    """A base's parameter table (cnn_param_shapes / mlp_param_shapes) with the OTHER head: the reference pairs either
+    base with either action space."""
+    out = OrderedDict((k, v) for k, v in shapes.items() if not k.startswith('dist.'))
+    out.update(head_param_shapes(hidden, num_actions, categorical))
+    return out
+
+
 def is_recurrent(P):
     return 'base.gru.weight_ih_l0' in P
 
@@ -152,12 +172,11 @@ def normal_logp_entropy(mean, logstd_bias, actions):
 
 def evaluate_actions(P, obs, actions, rnn_hxs=None, masks=None, return_hxs=False):
     """model.py:72-79: (value [B,1], action_log_probs [B,1], entropy.mean() scalar[, rnn_hxs])."""
-    if is_cnn(P):
-        value, feat, rnn_hxs = cnn_base(P, obs, rnn_hxs, masks)
+    value, feat, rnn_hxs = (cnn_base if is_cnn(P) else mlp_base)(P, obs, rnn_hxs, masks)
+    if is_categorical(P):            # the head follows the action space, not the base (model.py:30-38)
         logits = F.linear(feat, P['dist.linear.weight'], P['dist.linear.bias'])
         logp, ent = categorical_logp_entropy(logits, actions)
     else:
-        value, feat, rnn_hxs = mlp_base(P, obs, rnn_hxs, masks)
         mean = F.linear(feat, P['dist.fc_mean.weight'], P['dist.fc_mean.bias'])
         logp, ent = normal_logp_entropy(mean, P['dist.logstd._bias'], actions)
     if return_hxs:
@@ -167,13 +186,12 @@ def evaluate_actions(P, obs, actions, rnn_hxs=None, masks=None, return_hxs=False
 
 def act_deterministic(P, obs, rnn_hxs=None, masks=None):
     """model.py:54-66 with deterministic=True: (value, mode action, its log-prob, rnn_hxs)."""
-    if is_cnn(P):
-        value, feat, rnn_hxs = cnn_base(P, obs, rnn_hxs, masks)
+    value, feat, rnn_hxs = (cnn_base if is_cnn(P) else mlp_base)(P, obs, rnn_hxs, masks)
+    if is_categorical(P):
         logits = F.linear(feat, P['dist.linear.weight'], P['dist.linear.bias'])
         action = logits.argmax(dim=-1, keepdim=True)
         logp, _ = categorical_logp_entropy(logits, action)
     else:
-        value, feat, rnn_hxs = mlp_base(P, obs, rnn_hxs, masks)
         action = F.linear(feat, P['dist.fc_mean.weight'], P['dist.fc_mean.bias'])
         logp, _ = normal_logp_entropy(action, P['dist.logstd._bias'], action)
     return value, action, logp, rnn_hxs

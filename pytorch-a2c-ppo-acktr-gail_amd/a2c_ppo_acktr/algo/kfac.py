@@ -117,7 +117,7 @@ class KFACOptimizer(optim.Optimizer):
         for lname, (w, b) in layers.items():
             owner[id(w)] = (lname, 'w')
             owner[id(b)] = (lname, 'b')
-        if not engine.is_cnn(pol):
+        if pol.dist.kind == 1:
             owner[id(engine.logstd_param(pol))] = ('logstd', 'b')
         self._mods = []
         for module in pol.modules():
@@ -282,7 +282,8 @@ class KFACOptimizer(optim.Optimizer):
             noise = torch.randn(rows_total, 1)                    # CPU default generator, like the reference (F7)
             noise = noise.to(dev, non_blocking=True).view(-1)
         dls_rows = None
-        if not cnn:
+        gauss = pol.dist.kind == 1
+        if gauss:
             dls_rows = torch.empty(B, pol.dist.num_outputs, dtype=f32, device=dev)
         scratch_g = self.v_flat                                   # d logstd sum lands here; overwritten in step()
         engine.policy_loss(pol, acts, engine.ALGO_FISHER, actions, None, inv_batch, adv=noise, gather_idx=gather_idx,
@@ -296,6 +297,8 @@ class KFACOptimizer(optim.Optimizer):
             hp, hl = acts.dhead.data_ptr(), acts.dhead.shape[1]
             lin_g = {'fc': (acts.dfeat.data_ptr(), acts.dfeat.shape[1], acts.dfeat.shape[1]),
                      'critic': (hp, hl, 1), 'actor': (hp + 4, hl, A)}
+            if gauss:
+                lin_g['logstd'] = (dls_rows.data_ptr(), A, A)
         else:
             conv_g = {}
             A = pol.dist.num_outputs
@@ -303,8 +306,9 @@ class KFACOptimizer(optim.Optimizer):
                      'a2': (acts.dha2.data_ptr(), acts.dha2.shape[1], acts.dha2.shape[1]),
                      'c0': (acts.dhc1.data_ptr(), acts.dhc1.shape[1], acts.dhc1.shape[1]),
                      'c2': (acts.dhc2.data_ptr(), acts.dhc2.shape[1], acts.dhc2.shape[1]),
-                     'critic': (acts.dv.data_ptr(), 1, 1), 'mean': (acts.dmean.data_ptr(), A, A),
-                     'logstd': (dls_rows.data_ptr(), A, A)}
+                     'critic': (acts.dv.data_ptr(), 1, 1), 'mean': (acts.dmean.data_ptr(), A, A)}
+            if gauss:
+                lin_g['logstd'] = (dls_rows.data_ptr(), A, A)
         for m in self._mods:
             out = view_g(m)
             if m.layer in conv_g:

@@ -35,16 +35,22 @@ def is_cnn(policy):
     return hasattr(policy.base, 'main')
 
 
+def dist_linear(policy):
+    """The head's nn.Linear: `dist.linear` (Categorical: logits) or `dist.fc_mean` (DiagGaussian: mean) -- the reference
+    pairs either head with either base (model.py:30-38)."""
+    return policy.dist.linear if policy.dist.kind == 0 else policy.dist.fc_mean
+
+
 def cnn_layer_params(policy):
     m = policy.base.main
     return {'conv1': _wb(m[0]), 'conv2': _wb(m[2]), 'conv3': _wb(m[4]), 'fc': _wb(m[7]),
-            'critic': _wb(policy.base.critic_linear), 'actor': _wb(policy.dist.linear)}
+            'critic': _wb(policy.base.critic_linear), 'actor': _wb(dist_linear(policy))}
 
 
 def mlp_layer_params(policy):
     b = policy.base
     return {'a0': _wb(b.actor[0]), 'a2': _wb(b.actor[2]), 'c0': _wb(b.critic[0]), 'c2': _wb(b.critic[2]),
-            'critic': _wb(b.critic_linear), 'mean': _wb(policy.dist.fc_mean)}
+            'critic': _wb(b.critic_linear), 'mean': _wb(dist_linear(policy))}
 
 
 def logstd_param(policy):
@@ -439,7 +445,7 @@ FOLD_PAD = os.environ.get('ACKTR_FOLD_PAD', '1') != '0'
 def mlp_fused_ok(policy, B):
     """The fused single-workgroup step covers the reference's MuJoCo shape: non-recurrent MLPBase(hidden 64) with a
     DiagGaussian head, up to 64 rows.  Anything else runs layer by layer."""
-    if not FUSED_MLP or is_cnn(policy) or policy.is_recurrent or ops.profiler is not None:
+    if not FUSED_MLP or is_cnn(policy) or policy.is_recurrent or ops.profiler is not None or policy.dist.kind != 1:
         return False
     b = policy.base
     if hasattr(b.actor[0], 'add_bias'):            # KFAC's split_bias surgery: ACKTR needs the per-layer activations

@@ -59,14 +59,10 @@ class Policy(nn.Module):
         else:
             raise NotImplementedError
         self.obs_shape = tuple(obs_shape)
-        if isinstance(self.base, CNNBase):
-            if not isinstance(self.dist, Categorical):
-                raise NotImplementedError('CNNBase is built with the Categorical head (the Atari configuration)')
-            if tuple(obs_shape[1:]) != (84, 84):
-                raise NotImplementedError('CNNBase expects 84x84 frames (reference model.py:176-180)')
-        else:
-            if not isinstance(self.dist, DiagGaussian):
-                raise NotImplementedError('MLPBase is built with the DiagGaussian head (the MuJoCo configuration)')
+        if isinstance(self.base, CNNBase) and tuple(obs_shape[1:]) != (84, 84):
+            raise NotImplementedError('CNNBase expects 84x84 frames (reference model.py:176-180)')
+        if isinstance(self.dist, DiagGaussian) and num_outputs > 16:
+            raise NotImplementedError('DiagGaussian head: at most 16 action dimensions (csrc/loss.hip)')
         self._flatten_parameters()
 
     # ------------------------------------------------------------------ flat parameter storage
@@ -80,6 +76,8 @@ class Policy(nn.Module):
                 groups.append([w[name][1]])
             groups.append([w['critic'][0], w['actor'][0]])     # fused head weight [1+A, hidden]
             groups.append([w['critic'][1], w['actor'][1]])     # fused head bias   [1+A]
+            if self.dist.kind == 1:                            # CNN + Box: the state-independent logstd
+                groups.append([engine.logstd_param(self)])
             return groups
         return [[p] for p in self.parameters()]
 
@@ -148,21 +146,37 @@ class Policy(nn.Module):
         raise NotImplementedError
 
     def _dist_from_head(self, acts):
+        """torch-side view of the head's distribution (not used by act(); kept for user code that wants the object)."""
         if self.dist.kind == 0:
             return FixedCategorical(acts.dist_in())
         logstd = engine.logstd_param(self).detach().view(1, -1)
         return FixedNormal(acts.dist_in(), logstd.exp().expand_as(acts.dist_in()))
 
     def act(self, inputs, rnn_hxs, masks, deterministic=False):
-        """reference model.py:54-66 (rollout side; forward kernels without grad, sampling via torch RNG)."""
+        """reference model.py:54-66, rollout side: HIP forward without grad, then ONE head kernel (csrc/loss.hip
+        dist_act_kernel) for mode / sample and the log-prob of the chosen action.  Sampling noise comes from torch's
+        device generator (uniform [B] for Categorical, standard normal [B, A] for DiagGaussian): same distributions as
+        the reference's multinomial / normal draws, not the same random stream."""
+        from . import _hip
         with torch.no_grad():
             acts = engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks)
-            dist = self._dist_from_head(acts)
-            action = dist.mode() if deterministic else dist.sample()
-            action_log_probs = dist.log_probs(action)
+            dev = inputs.device
+            B, A, kind = inputs.shape[0], self.dist.num_outputs, self.dist.kind
+            noise = None
+            if not deterministic:
+                noise = torch.rand(B, device=dev) if kind == 0 else torch.randn(B, A, device=dev)
+            action = torch.empty((B, 1), dtype=torch.int64, device=dev) if kind == 0 else \
+                torch.empty((B, A), dtype=torch.float32, device=dev)
+            logp = torch.empty(B, 1, dtype=torch.float32, device=dev)
+            ls = engine.logstd_param(self).detach() if kind == 1 else None
+            dp, dld = acts.dist_ptr_ld()
+            rc = _hip.lib().acktr_dist_act_f32(kind, dp, dld, _hip.dev_ptr(ls), _hip.dev_ptr(noise),
+                                               1 if deterministic else 0, B, A, _hip.dev_ptr(action, action.dtype),
+                                               _hip.dev_ptr(logp), _hip.cur_stream(dev))
+            _hip.check(rc, 'acktr_dist_act_f32')
             if self.is_recurrent:
                 rnn_hxs = acts.hxs_out.clone()
-            return acts.value().clone(), action, action_log_probs, rnn_hxs
+            return acts.value().clone(), action, logp, rnn_hxs
 
     def get_value(self, inputs, rnn_hxs, masks):
         """reference model.py:68-70."""

@@ -121,6 +121,52 @@ __global__ __launch_bounds__(LOSS_THREADS) void dist_fwd_kernel(const float* dis
     entropy[b] = d.ent;
 }
 
+// Rollout-side head (Policy.act, model.py:54-66): mode or a sample of the action distribution and the log-prob of
+// the chosen action, one sample per lane.
+//   categorical: mode = first argmax of the logits (torch.argmax); sample = inverse CDF of softmax(logits) at the
+//                caller's uniform u[b] in [0, 1) (one draw per row, like FixedCategorical.sample's multinomial(1));
+//   gaussian   : mode = mean; sample = mean + std * eps with the caller's standard normal eps[b, j] (torch.normal's
+//                own formula, FixedNormal.sample); the log-prob follows torch Normal.log_prob term by term.
+template <int DIST>
+__global__ __launch_bounds__(LOSS_THREADS) void dist_act_kernel(const float* dist_in, long ld, const float* logstd,
+                                                                const float* noise, int deterministic, int B, int A,
+                                                                void* action_out, float* logp) {
+    const int b = blockIdx.x * LOSS_THREADS + threadIdx.x;
+    if (b >= B) return;
+    const float* z = dist_in + (long)b * ld;
+    if (DIST == 0) {
+        float m = z[0];
+        int am = 0;
+        for (int i = 1; i < A; ++i) if (z[i] > m) { m = z[i]; am = i; }
+        float ssum = 0.f;
+        for (int i = 0; i < A; ++i) ssum += expf(z[i] - m);
+        const float lse = m + logf(ssum);
+        int a = am;
+        if (!deterministic) {
+            const float target = noise[b] * ssum;          // u * sum_i exp(z_i - m): no division per category
+            float acc = 0.f;
+            a = A - 1;
+            for (int i = 0; i < A; ++i) {
+                acc += expf(z[i] - m);
+                if (target < acc) { a = i; break; }
+            }
+        }
+        ((int64_t*)action_out)[b] = a;
+        logp[b] = z[a] - lse;
+    } else {
+        float lp = 0.f;
+        float* out = (float*)action_out + (long)b * A;
+        for (int j = 0; j < A; ++j) {
+            const float sd = expf(logstd[j]);
+            const float act = deterministic ? z[j] : z[j] + sd * noise[(long)b * A + j];
+            const float var = sd * sd, d = act - z[j];
+            lp += -(d * d) / (2.f * var) - logf(sd) - HALF_LOG_2PI;
+            out[j] = act;
+        }
+        logp[b] = lp;
+    }
+}
+
 template <int DIST>
 __global__ __launch_bounds__(LOSS_THREADS) void dist_bwd_kernel(const float* dist_in, long ld, const float* logstd,
                                                                 const void* actions, const float* dlogp,
@@ -214,6 +260,24 @@ extern "C" int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const
     else
         hipLaunchKernelGGL((dist_fwd_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, B, A,
                            logp, entropy);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_dist_act_f32(int dist, const float* dist_in, long ld, const float* logstd, const float* noise,
+                                  int deterministic, int B, int A, void* action_out, float* logp, void* stream) {
+    ACKTR_ARG(dist_in && action_out && logp, "dist_act: null pointer");
+    ACKTR_ARG(B > 0 && A > 0 && ld >= A, "dist_act: bad sizes");
+    ACKTR_ARG(dist == 0 || (dist == 1 && logstd && A <= 16), "dist_act: bad distribution arguments");
+    ACKTR_ARG(deterministic || noise, "dist_act: sampling needs the noise array (uniform [B] / standard normal [B,A])");
+    hipStream_t s = (hipStream_t)stream;
+    const int nblk = cdiv(B, LOSS_THREADS);
+    if (dist == 0)
+        hipLaunchKernelGGL((dist_act_kernel<0>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, noise,
+                           deterministic, B, A, action_out, logp);
+    else
+        hipLaunchKernelGGL((dist_act_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, noise,
+                           deterministic, B, A, action_out, logp);
     ACKTR_LAUNCH_CHECK();
     return 0;
 }

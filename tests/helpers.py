@@ -241,3 +241,24 @@ def rec_eval_inputs(ci):
                 hxs=ro['recurrent_hidden_states'][0], masks=ro['masks'][:-1].reshape(B, 1),
                 vp=ro['value_preds'][:-1].reshape(B, 1), ret=synth.normalish((B, 1), 1950 + ci),
                 adv=synth.normalish((B, 1), 1960 + ci)), ro
+
+
+# ------------------------------------------------------------------------------------------ rollout side + base x head pairings
+# mirrors tests/golden/make_golden_act.py: tag, base, obs dim, categorical head?, A, B
+ACT_CASES = [('cnn_cat', 'cnn', None, True, 6, 9), ('mlp_gauss', 'mlp', 11, False, 3, 16),
+             ('cnn_gauss', 'cnn', None, False, 4, 5), ('mlp_cat', 'mlp', 17, True, 5, 12)]
+
+
+def act_shapes(kind, od, cat, A):
+    from oracle import policy_ref
+    base = policy_ref.cnn_param_shapes(4, 512, A) if kind == 'cnn' else policy_ref.mlp_param_shapes(od, 64, A)
+    return policy_ref.with_head(base, 512 if kind == 'cnn' else 64, A, cat)
+
+
+def act_case_inputs(ci):
+    """(params dict, obs, rollout dict) of ACT_CASES[ci], regenerated from synth."""
+    tag, kind, od, cat, A, B = ACT_CASES[ci]
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    P = synth.make_params(act_shapes(kind, od, cat, A), 140 + ci)
+    ro = synth.make_rollouts(1, B, obs_shape, 'discrete' if cat else 'box', A, salt=1400 + ci)
+    return P, ro['obs'][0], ro

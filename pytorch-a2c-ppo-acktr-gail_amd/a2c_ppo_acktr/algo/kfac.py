@@ -108,6 +108,7 @@ class KFACOptimizer(optim.Optimizer):
         self.dp = DataParallel()          # replaced by A2C_ACKTR with its own context
         self._ext_noise = None
         self._side_stream = None
+        self._bcast_buf = None
 
     # ------------------------------------------------------------------ module discovery (kfac.py:179-188)
     def _prepare_model(self):
@@ -384,14 +385,29 @@ class KFACOptimizer(optim.Optimizer):
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
         if self.dp.active:
-            # every factor was decomposed by exactly one rank: zero the slots this rank does not own and SUM
-            # all-reduce the four flat buckets (= a broadcast from each owner in one collective per bucket)
-            for (run, qt, dfl, off, doff, n), own in zip(self._eig_work, self._eig_owner):
+            # every factor was decomposed by exactly one rank: each owner packs its (Q^T, d) slots into one contiguous
+            # message and broadcasts it -- 16.7 MB in total for NatureCNN, one collective per owner (round 1 zeroed the
+            # foreign slots and SUM all-reduced the four whole buckets: 33 MB through a reduction nobody needed)
+            per_owner = {}
+            for w, own in zip(self._eig_work, self._eig_owner):
+                per_owner.setdefault(own, []).append(w)
+            for own in sorted(per_owner):
+                segs = []
+                for run, qt, dfl, off, doff, n in per_owner[own]:
+                    segs.append(qt[off:off + n * n])
+                    segs.append(dfl[doff:doff + n])
+                total = sum(t_.numel() for t_ in segs)
+                if self._bcast_buf is None or self._bcast_buf.numel() < total:
+                    self._bcast_buf = torch.empty(total, dtype=f32, device=dev)
+                buf = self._bcast_buf[:total]
+                if own == self.dp.rank:
+                    torch.cat(segs, out=buf)
+                self.dp.broadcast_(buf, src=own)
                 if own != self.dp.rank:
-                    qt[off:off + n * n].zero_()
-                    dfl[doff:doff + n].zero_()
-            for buf in (self.qt_a, self.qt_g, self.d_a_flat, self.d_g_flat):
-                self.dp.all_reduce_sum_(buf)
+                    o = 0
+                    for t_ in segs:
+                        t_.copy_(buf[o:o + t_.numel()])
+                        o += t_.numel()
 
     # ------------------------------------------------------------------ step (kfac.py:190-242)
     def step(self):

@@ -106,6 +106,20 @@ class Policy(nn.Module):
         self.__dict__['flat_grads'] = gflat
         self.__dict__['_offsets'] = offs
 
+    # checkpoints: the reference pickles the whole module (main.py:165-176, enjoy.py:52-54).  The flat buffers and
+    # the id()-keyed offset table are derived state: they are left out of the pickle and rebuilt from the parameters.
+    _DERIVED = ('flat_params', 'flat_grads', '_offsets', '_pack_ws')
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        for k in self._DERIVED:
+            state.pop(k, None)
+        return state
+
+    def __setstate__(self, state):
+        super(Policy, self).__setstate__(state)
+        self._flatten_parameters()
+
     def _apply(self, fn, *args, **kwargs):
         r = super(Policy, self)._apply(fn, *args, **kwargs)
         self._flatten_parameters()

@@ -34,12 +34,13 @@ def _worker(rank, world, port, out_dir, algo_name, backend='gloo'):
     from helpers import t
     from test_policy_gpu import Discrete, make_storage
     import datetime
-    torch.cuda.set_device(0)
+    dev = rank if (backend == 'nccl' and world > 1) else 0      # real multi-GPU: one device per rank
+    torch.cuda.set_device(dev)
     if world > 1 or backend == 'nccl':
         os.environ['MASTER_ADDR'] = '127.0.0.1'
         os.environ['MASTER_PORT'] = str(port)
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        kw = dict(device_id=torch.device('cuda', 0)) if backend == 'nccl' else {}
+        kw = dict(device_id=torch.device('cuda', dev)) if backend == 'nccl' else {}
         dist.init_process_group(backend, rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60), **kw)
     from a2c_ppo_acktr import algo
     from a2c_ppo_acktr.model import Policy
@@ -67,7 +68,7 @@ def _worker(rank, world, port, out_dir, algo_name, backend='gloo'):
         agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
         agent.optimizer.Tf = 2
         n_upd = 3
-    if backend == 'nccl':                                # one rank, but through the data-parallel code path on RCCL
+    if backend == 'nccl' and world == 1:                 # one rank, but through the data-parallel code path on RCCL
         from a2c_ppo_acktr.parallel import DataParallel
         agent.dp = DataParallel(force_active=True)
         if hasattr(agent.optimizer, 'dp'):
@@ -111,6 +112,22 @@ def test_rccl_collectives_single_rank(tmp_path, algo_name):
     mp.spawn(_worker, args=(1, _free_port(), out, algo_name, 'nccl'), nprocs=1, join=True)
     one = torch.load(os.path.join(out, '%s_w1.pt' % algo_name))
     two = torch.load(os.path.join(out, '%s_w1_rccl.pt' % algo_name))
+    np.testing.assert_allclose(two['losses'].numpy(), one['losses'].numpy(), rtol=2e-4, atol=1e-6)
+    err = float((two['flat'] - one['flat']).norm() / one['flat'].norm())
+    assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: two ranks over real RCCL (xGMI)')
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'ppo_rec'])
+def test_two_rank_update_matches_single_process_rccl(tmp_path, algo_name):
+    """The same check with one GPU per rank and the `nccl` (= RCCL) backend: runs wherever the box has two GPUs (the
+    driver's multi-GPU node), skips on a one-GPU box.  Exercises what gloo cannot: in-place device all-reduces on RCCL's
+    stream, the asynchronous late-bucket all-reduce overlapped with the backward, owner broadcasts of the eigenbases."""
+    out = str(tmp_path)
+    mp.spawn(_worker, args=(1, 0, out, algo_name), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, algo_name, 'nccl'), nprocs=2, join=True)
+    one = torch.load(os.path.join(out, '%s_w1.pt' % algo_name))
+    two = torch.load(os.path.join(out, '%s_w2_rccl.pt' % algo_name))
     np.testing.assert_allclose(two['losses'].numpy(), one['losses'].numpy(), rtol=2e-4, atol=1e-6)
     err = float((two['flat'] - one['flat']).norm() / one['flat'].norm())
     assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err

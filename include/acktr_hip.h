@@ -322,6 +322,12 @@ int acktr_gail_reward_f32(const float* d, long n, float* reward, void* stream);
  * moments[S][2] = {mean, population variance} in fp64 that RunningMeanStd.update merges. */
 int acktr_gail_returns_moments_f32(const float* reward, const float* masks, int S, int N, float gamma, float* ret_io,
                                    float* ret_steps, double* moments, void* stream);
+/* gail.py:108-110 for S consecutive steps: RunningMeanStd.update_from_moments (stable_baselines3's published parallel
+ * mean / variance merge, fp64) applied to moments[s] = {mean, population variance} of batch_count samples each, in step
+ * order, on state_inout = {mean, var, count}; scale_out[s] = sqrt(var after step s + 1e-8).  One lane: the merge is a
+ * scalar recurrence (the reference does it on the host, one call and one host sync per rollout step). */
+int acktr_gail_rms_merge_f64(const double* moments, int S, double batch_count, double* state_inout, float* scale_out,
+                             void* stream);
 /* gail.py:110: reward[s, :] /= scale[s]. */
 int acktr_gail_scale_rows_f32(float* reward, const float* scale, int S, int N, void* stream);
 

@@ -122,6 +122,7 @@ _PROTOS = {
     'acktr_gail_tanh_link_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p]),
     'acktr_gail_reward_f32': (c_i, [c_p, c_l, c_p, c_p]),
     'acktr_gail_returns_moments_f32': (c_i, [c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'acktr_gail_rms_merge_f64': (c_i, [c_p, c_i, ctypes.c_double, c_p, c_p, c_p]),
     'acktr_gail_scale_rows_f32': (c_i, [c_p, c_p, c_i, c_i, c_p]),
     'acktr_mlp_fused_step_supported': (c_i, [c_i, c_i, c_i, c_i]),
     'acktr_mlp_fused_step_f32': (c_i, [ctypes.POINTER(MlpStepArgs), c_p]),

@@ -274,13 +274,20 @@ class Discriminator(nn.Module):
                                                     _hip.dev_ptr(mom, torch.float64), _hip.cur_stream(dev)),
                    'acktr_gail_returns_moments_f32')
         self.returns = ret_io.view(-1, 1)
-        mom_h = mom.cpu().numpy()                                       # S x {mean, var}: the sequential merge is scalar work
-        scale = np.empty(S, np.float32)
-        for s in range(S):
-            self.ret_rms.update_from_moments(mom_h[s, 0:1], mom_h[s, 1:2], N)
-            scale[s] = np.sqrt(self.ret_rms.var[0] + 1e-8)
+        # RunningMeanStd merge of the S per-step moments on the device (one lane, fp64, the numpy restatement's operation
+        # order) -- round 1 pulled the moments to the host and merged them in a Python loop, half of the 14 ms of a
+        # 2048-step rollout; the public `ret_rms` object is refreshed from the 24-byte state afterwards
+        first = lambda a: float(np.asarray(a, np.float64).reshape(-1)[0])
+        state = torch.tensor([first(self.ret_rms.mean), first(self.ret_rms.var), first(self.ret_rms.count)],
+                             dtype=torch.float64).to(dev)
+        sc = torch.empty(S, dtype=f32, device=dev)
+        _hip.check(L.acktr_gail_rms_merge_f64(_hip.dev_ptr(mom, torch.float64), S, float(N),
+                                              _hip.dev_ptr(state, torch.float64), _hip.dev_ptr(sc), _hip.cur_stream(dev)),
+                   'acktr_gail_rms_merge_f64')
+        st_h = state.cpu().numpy()
+        # (shape (1,) like the reference's after `ret_rms.update(returns[N,1])`, gail.py:107-110 reads `var[0]`)
+        self.ret_rms.mean, self.ret_rms.var, self.ret_rms.count = st_h[0:1].copy(), st_h[1:2].copy(), float(st_h[2])
         out = reward.clone()
-        sc = torch.from_numpy(scale).to(dev)
         _hip.check(L.acktr_gail_scale_rows_f32(_hip.dev_ptr(out), _hip.dev_ptr(sc), S, N, _hip.cur_stream(dev)),
                    'acktr_gail_scale_rows_f32')
         return out

@@ -218,6 +218,35 @@ extern "C" int acktr_gail_returns_moments_f32(const float* reward, const float* 
     return 0;
 }
 
+// RunningMeanStd.update_from_moments for S consecutive batches (gail.py:108-110 called once per rollout step): the merge
+// is a scalar recurrence in fp64, so ONE lane walks the S steps (same operation order as the numpy restatement in
+// a2c_ppo_acktr/algo/gail.py) and writes scale[s] = sqrt(var_after_step_s + 1e-8) for gail.py:110.
+__global__ void gail_rms_merge_kernel(const double* moments, int S, double batch_count, double* state, float* scale) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double mean = state[0], var = state[1], count = state[2];
+    for (int s = 0; s < S; ++s) {
+        const double bm = moments[2 * s], bv = moments[2 * s + 1];
+        const double delta = bm - mean;
+        const double tot = count + batch_count;
+        const double new_mean = mean + delta * batch_count / tot;
+        const double m_2 = var * count + bv * batch_count + delta * delta * count * batch_count / tot;
+        mean = new_mean;
+        var = m_2 / tot;
+        count = tot;
+        scale[s] = (float)sqrt(var + 1e-8);
+    }
+    state[0] = mean; state[1] = var; state[2] = count;
+}
+
+extern "C" int acktr_gail_rms_merge_f64(const double* moments, int S, double batch_count, double* state_inout,
+                                        float* scale_out, void* stream) {
+    ACKTR_ARG(moments && state_inout && scale_out && S > 0 && batch_count > 0, "gail_rms_merge: bad arguments");
+    hipLaunchKernelGGL(gail_rms_merge_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments, S, batch_count,
+                       state_inout, scale_out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int acktr_gail_scale_rows_f32(float* reward, const float* scale, int S, int N, void* stream) {
     ACKTR_ARG(reward && scale && S > 0 && N > 0, "gail_scale_rows: bad arguments");
     hipLaunchKernelGGL(gail_scale_rows_kernel, dim3(ew_grid((long)S * N)), dim3(256), 0, (hipStream_t)stream, reward, scale, S, N);

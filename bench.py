@@ -383,9 +383,12 @@ def main():
     # Per-kernel durations: the timed region above replays a captured hipGraph (no host launches to bracket), so
     # the same update is run once more launch-by-launch with HIP events around every GEMM-class operator on the
     # launch stream (same kernels, shapes, buffers).  rocprofv3 of this command (profiles/) sees both.
-    ops.profiler = {}
-    torch.manual_seed(300)
-    agent.update(rs)
+    # (run twice, the first pass un-recorded: the eager launches allocate their outputs outside the graph's private
+    # pool, and a first-touch hipMalloc inside an event bracket showed up as a 1 ms conv2 forward)
+    for _ in range(2):
+        ops.profiler = {}
+        torch.manual_seed(300)
+        agent.update(rs)
     prof = ops.profile_summary()
     ops.profiler = None
     if world > 1:

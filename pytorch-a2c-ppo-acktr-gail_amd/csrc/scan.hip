@@ -3,7 +3,7 @@
 // compute_returns restates a2c_ppo_acktr/storage.py:66-105 of the reference:
 // a serial-in-t recurrence per environment whose fp32 association must be kept
 // (bit-exact contract), so time cannot be parallelised.  Design for MI355X:
-//   * one lane per environment, 32 environments per workgroup (128-B rows);
+//   * one lane per environment, 32 (or 16, see ScanCfg) environments per workgroup (128-B rows);
 //   * all 4 waves of the workgroup prefetch the NEXT 64-step chunk straight to
 //     registers and pre-compute everything that does not depend on the carried
 //     value (delta, gamma*lambda*mask, (1-bad)*V) -> LDS, double buffered;
@@ -16,6 +16,7 @@
 // products and sums are rounded separately, exactly as the reference's separate torch ops do.
 // Plain operators are used on purpose: the __f*_rn() header wrappers are compiled under the
 // header's own contraction mode and DO fuse into v_fma after inlining.
+#include <stdlib.h>
 #include <mutex>
 #include <type_traits>
 
@@ -26,20 +27,25 @@
 
 namespace acktr {
 
-constexpr int SCAN_TE = 32;   // environments per workgroup
-constexpr int SCAN_TC = 64;   // time steps per chunk
 constexpr int SCAN_LOADERS = 256;                            // waves 1..4: HBM loads, staging, result write-back
 constexpr int SCAN_THREADS = 64 + SCAN_LOADERS;              // wave 0: the dependent chain, nothing else
-constexpr int SCAN_EPT = SCAN_TE * SCAN_TC / SCAN_LOADERS;   // elements per loader thread per chunk (8)
-constexpr int SCAN_PITCH = SCAN_TC + 4;                      // LDS row (one environment's chunk) pitch, 16-byte multiple
 typedef float scan_f4 __attribute__((ext_vector_type(4)));
 
-template <bool GAE, bool PROPER>
+// TE environments per workgroup x TC time steps per chunk.  32 x 64 (128-byte rows) when N gives >= 128 workgroups;
+// below that 16 x 128: the chain is latency-bound whatever the number of active lanes, and twice as many workgroups
+// (CUs) pull the rollout from HBM -- at T = 2048 x N = 1024 the 32 workgroups of the 32-wide form were load-bound
+// (44.5 us; 16 x 128: 33.2 us = 16 ns per step, 8 x 128: 32.6 us -- the dependent chain of 3 roundings per step is the
+// floor now; at N = 65536 the narrow forms lose 35-60 % of the bandwidth, so they are used for small N only).
+template <bool GAE, bool PROPER, int TE_, int TC_>
 struct ScanCfg {
+    static constexpr int TE = TE_, TC = TC_;
+    static constexpr int EPT = TE * TC / SCAN_LOADERS;       // elements per loader thread per chunk (8)
+    static constexpr int PITCH = TC + 4;                     // LDS row (one environment's chunk) pitch, 16-byte multiple
     static constexpr int NARR = PROPER ? 4 : (GAE ? 3 : 2);
-    static constexpr int IN_FLOATS = 2 * NARR * SCAN_TE * SCAN_PITCH;     // double-buffered chain operands
-    static constexpr int OUT_FLOATS = 2 * SCAN_TE * SCAN_PITCH;           // double-buffered results
+    static constexpr int IN_FLOATS = 2 * NARR * TE * PITCH;  // double-buffered chain operands
+    static constexpr int OUT_FLOATS = 2 * TE * PITCH;        // double-buffered results
     static constexpr int LDS_BYTES = (IN_FLOATS + OUT_FLOATS) * (int)sizeof(float);
+    static_assert(EPT % 4 == 0 && TE % 4 == 0 && (TE * TC) % SCAN_LOADERS == 0 && TE <= 64, "scan tile");
 };
 
 // Roles inside a workgroup, per 64-step chunk c (all overlapped, one barrier per chunk):
@@ -56,12 +62,12 @@ struct ScanCfg {
 // environments, one 16-byte load per array and quad -- 10 loads per chunk instead of 40, so three chunks of prefetch fit
 // under the 64 outstanding vector-memory operations a wave can have (with 40 per chunk the issue itself stalled and the
 // loaders, not the chain, set the pace: 52 us against 28 us for the chain alone at T = 2048).  VEC = 1: any N.
-template <bool GAE, bool PROPER, int VEC>
+template <bool GAE, bool PROPER, int VEC, int TE, int TC>
 __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
     const float* rewards, float* value_preds, float* returns, const float* masks, const float* bad_masks,
     const float* next_value, int T, int N, float g, float gl) {
-    using Cfg = ScanCfg<GAE, PROPER>;
-    constexpr int NARR = Cfg::NARR;
+    using Cfg = ScanCfg<GAE, PROPER, TE, TC>;
+    constexpr int NARR = Cfg::NARR, SCAN_TE = TE, SCAN_TC = TC, SCAN_EPT = Cfg::EPT, SCAN_PITCH = Cfg::PITCH;
     extern __shared__ __attribute__((aligned(16))) float scan_lds[];
     float* lin = scan_lds;                          // [2][NARR][SCAN_TE][SCAN_PITCH]
     float* lout = scan_lds + Cfg::IN_FLOATS;        // [2][SCAN_TE][SCAN_PITCH]
@@ -254,14 +260,8 @@ __global__ __launch_bounds__(SCAN_THREADS) void returns_scan_kernel(
         stage_to_lds(std::integral_constant<int, (p + 1) % 3>{}, (c + 1) & 1);
     };
     auto step = [&](auto P, int c) {
-#if defined(SCAN_DBG_NOLOAD)
-        if (tid >= 64) { }
-#else
         if (tid >= 64) loader_step(P, c);
-#endif
-#if !defined(SCAN_DBG_NOCHAIN)
         else if (tid < SCAN_TE) chain(c & 1);
-#endif
         __syncthreads();
     };
     for (int c = 0; c < nchunks; c += 3) {
@@ -353,24 +353,30 @@ extern "C" int acktr_compute_returns_f32(const float* rewards, float* value_pred
     ACKTR_ARG(T > 0 && N > 0, "compute_returns: T=%d N=%d must be positive", T, N);
     ACKTR_ARG((long)(T + 1) * N < (1L << 31), "compute_returns: (T+1)*N too large");
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(cdiv(N, SCAN_TE)), block(SCAN_THREADS);
+    dim3 block(SCAN_THREADS);
+    int te = (cdiv(N, 32) < 128 && N > 16) ? 16 : 32;         // few environments: 16 per workgroup, 128-step chunks
+    if (const char* ev = getenv("ACKTR_SCAN_TE")) te = atoi(ev);   // tuning override (tools/scan_bench.py)
     const uintptr_t al = (uintptr_t)rewards | (uintptr_t)value_preds | (uintptr_t)returns | (uintptr_t)masks |
                          (uintptr_t)(use_proper_time_limits ? bad_masks : rewards);
     const bool vec4 = (N % 4 == 0) && (al % 16 == 0);
-#define LAUNCH(G, P, V)                                                                                              \
+#define LAUNCH(G, P, V, TE, TC)                                                                                      \
     do {                                                                                                             \
-        constexpr int lds_bytes = ScanCfg<G, P>::LDS_BYTES;                                                          \
+        constexpr int lds_bytes = ScanCfg<G, P, TE, TC>::LDS_BYTES;                                                  \
         static bool attr_set = false;                                                                                \
         if (!attr_set && lds_bytes > 48 * 1024) {                                                                    \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(returns_scan_kernel<G, P, V>),          \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(returns_scan_kernel<G, P, V, TE, TC>),  \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);               \
             ACKTR_ARG(e == hipSuccess, "compute_returns: hipFuncSetAttribute failed: %s", hipGetErrorString(e));     \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((returns_scan_kernel<G, P, V>), grid, block, lds_bytes, s, rewards, value_preds, returns, \
-                           masks, bad_masks, next_value, T, N, gamma32, gamma_lambda32);                             \
+        hipLaunchKernelGGL((returns_scan_kernel<G, P, V, TE, TC>), dim3(cdiv(N, TE)), block, lds_bytes, s, rewards,  \
+                           value_preds, returns, masks, bad_masks, next_value, T, N, gamma32, gamma_lambda32);       \
     } while (0)
-#define LAUNCHV(G, P) do { if (vec4) LAUNCH(G, P, 4); else LAUNCH(G, P, 1); } while (0)
+#define LAUNCHV(G, P)                                                             \
+    do {                                                                          \
+        if (te == 16) { if (vec4) LAUNCH(G, P, 4, 16, 128); else LAUNCH(G, P, 1, 16, 128); } \
+        else { if (vec4) LAUNCH(G, P, 4, 32, 64); else LAUNCH(G, P, 1, 32, 64); }  \
+    } while (0)
     if (use_gae) {
         if (use_proper_time_limits) LAUNCHV(true, true); else LAUNCHV(true, false);
     } else {

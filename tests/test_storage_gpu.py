@@ -40,7 +40,9 @@ def test_compute_returns_bit_exact_vs_reference_golden(T, N, use_gae, proper):
                           G[key + '/value_preds_last'].view(np.uint32))
 
 
-@pytest.mark.parametrize('T,N', [(1, 1), (63, 31), (64, 32), (65, 100), (700, 257)])
+# (N <= 16 and N >= 4065 run the 32-environment form of the kernel, everything between the 16-environment form; 4100 / 4099
+# cover its 16-byte and scalar loaders with a ragged last workgroup, 130 / 300 / 700 the chunk tails of both forms)
+@pytest.mark.parametrize('T,N', [(1, 1), (63, 31), (64, 32), (65, 100), (700, 257), (130, 4100), (67, 4099), (300, 12)])
 @pytest.mark.parametrize('mode', [(0, 0), (0, 1), (1, 0), (1, 1)])
 def test_compute_returns_bit_exact_vs_oracle_ragged(T, N, mode):
     use_gae, proper = mode

@@ -125,6 +125,36 @@ static int conv3_wgrad_sa(const float* x, const float* dy, float* dw, float* db,
     return launch_slab_reduce(db, ws + wk, ns, SA_OC, slab, 1.f, 0, s);
 }
 
+// 8x8 stride-4 layer on 84x84x4 frames with OC == 32: stationary accumulators, one workgroup per CU (conv_wgrad_sa.hpp)
+static bool sa1_wgrad_ok(int geom, int C, int OC, int B) {
+    static const bool off = getenv("ACKTR_CONV1_WGRAD_TILE") != nullptr;     // tuning / comparison switch
+    return !off && geom == GEOM_8S4 && C == S1_C && OC == S1_OC && B >= 64;
+}
+static int sa1_wgrad_slabs(int B) {
+    const int cus = sw_num_cus();
+    const int by_work = B * S1_GROUPS / 40;            // at least ten row-pair groups per wave
+    return by_work < cus ? (by_work < 1 ? 1 : by_work) : cus;
+}
+static int conv1_wgrad_sa(const float* x, const int64_t* idx, const float* dy, float* dw, float* db, int B, float scale,
+                          float* ws, long ws_floats, hipStream_t s) {
+    const long wk = (long)S1_OC * S1_KC, slab = wk + S1_OC;
+    const int ns = sa1_wgrad_slabs(B);
+    if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_wgrad_sa_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES);
+        if (e != hipSuccess) { set_error("conv1_wgrad_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(conv1_wgrad_sa_kernel, dim3(ns), dim3(64 * S1_WAVES), S1_LDS_BYTES, s, x, idx, dy, ws, slab, B, scale);
+    ACKTR_LAUNCH_CHECK();
+    if (db == dw + wk) return launch_slab_reduce(dw, ws, ns, wk + S1_OC, slab, 1.f, 0, s);
+    int rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
+    if (rc || !db) return rc;
+    return launch_slab_reduce(db, ws + wk, ns, S1_OC, slab, 1.f, 0, s);
+}
+
 // dgrad weights re-packed once per call into dense per-phase matrices Wp[phase][c][k], k = (oc, a, a'), rows padded
 // to a multiple of 4: the GEMM's M operand then streams 16-byte rows instead of gathering 4-byte taps that sit
 // KH*KW*C floats apart (one cache line per lane).
@@ -311,6 +341,7 @@ extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, i
     const int OWP = (OW + 3) / 4 * 4;      // the stride-1 path reduces over padded positions
     int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OWP, 1024);
     if (sa_wgrad_ok(geom_of(H, W, KH, KW, S), C, OC, nullptr) && sa_wgrad_slabs(B) > ns) ns = sa_wgrad_slabs(B);
+    if (sa1_wgrad_ok(geom_of(H, W, KH, KW, S), C, OC, B) && sa1_wgrad_slabs(B) > ns) ns = sa1_wgrad_slabs(B);
     return (long)(ns + SLAB_GROUP_EXTRA) * wgrad_slab_floats(OC, Kc) * (long)sizeof(float);
 }
 
@@ -327,6 +358,10 @@ extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx,
 #define WG(KH_, KW_, S_, H_, W_)                                                                                  \
     (OC <= 32 ? conv_wgrad_t<KH_, KW_, S_, H_, W_, 32, 1, 4>(x, gather_idx, dy, dw, db, B, C, OC, in_scale, ws, wf, s) \
               : conv_wgrad_t<KH_, KW_, S_, H_, W_, 64, 2, 2>(x, gather_idx, dy, dw, db, B, C, OC, in_scale, ws, wf, s))
+    if (sa1_wgrad_ok(geom, C, OC, B)) {
+        const int rc = conv1_wgrad_sa(x, gather_idx, dy, dw, db, B, in_scale, ws, wf, s);
+        if (rc != -2) return rc;
+    }
     if (geom == GEOM_8S4) return WG(8, 8, 4, 84, 84);
     if (geom == GEOM_4S2) return WG(4, 4, 2, 20, 20);
     if (gather_idx) return WG(3, 3, 1, 9, 9);

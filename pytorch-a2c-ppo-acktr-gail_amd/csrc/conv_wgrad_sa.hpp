@@ -118,4 +118,135 @@ __global__ __launch_bounds__(C * SA_KK) void conv3_wgrad_sa_kernel(const float* 
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stationary-accumulator weight gradient of the 8x8 stride-4 layer on 84x84x4 frames (reference model.py:176, its
+// autograd backward; the dominant kernel of the PPO step):
+//   dW[oc, (c,ky,kx)] = scale * sum_{b,oy,ox} dY[b,oc,oy,ox] * X[idx[b],c,4oy+ky,4ox+kx],   db[oc] = sum dY.
+// The tile GEMM ran this 32 x 256 x (B*400) product at 74 TFLOP/s: two output tiles, so the reduction is cut into
+// ~400 slices whose workgroups each pay a pipeline fill, two barriers per K-tile pair and an im2col address decode per
+// element.  Here the whole dW lives in accumulators and both operands go from global memory straight into the
+// registers the MFMA reads (no LDS, no barrier in the loop):
+//   * a wave owns 32 oc x 128 taps = channels {2nh, 2nh+1} as FOUR interleaved 32x32 tiles: lane (li, h) stands for the
+//     tap group (c = 2nh + li/16, ky = (li/2)%8, kx = 4(li%2) .. +3) and tile q takes kx = 4(li%2) + q -- the four
+//     floats of ONE aligned 16-byte load of the frame row are the B values of the four tiles;
+//   * the reduction runs over blocks of 8 output positions; lane half h takes positions 4h .. 4h+3 of the block, which
+//     lie in one output row (20 % 4 == 0), so they are 4 consecutive 16-byte loads of the same frame row (one
+//     64-byte run per lane) and ONE 16-byte load of dY[b, li, ...] for A;
+//   * five blocks = 40 positions = two output rows: with the loop unrolled by five every lane offset is a constant of
+//     the ring slot, only the image pointer and the row pair t move (scalar).  The ring keeps five blocks (25 loads)
+//     in flight per wave, two waves per SIMD.
+// A workgroup is 8 waves = 2 channel halves x 4 reduction sub-ranges; the four partial sums of a half are added in LDS
+// in a fixed order and ONE slab per workgroup (one workgroup per CU) goes to the shared slab reduction: 8 MB of slabs
+// instead of 12.6.  Measured at B = 1024 (MI355X): 90.4 -> 77.5 us per call inside the PPO step (86.6 TFLOP/s); with the
+// MFMAs removed the loop takes 30 us (115 MB of frames + 52 MB of dY from HBM), with the loads removed 45 us -- the two
+// overlap only partly, the sum of both pipes is what is left to gain.
+constexpr int S1_C = 4, S1_H = 84, S1_OC = 32, S1_SP = 400, S1_KC = 256, S1_GROUPS = 10, S1_WAVES = 8;
+constexpr int S1_LDS_BYTES = S1_WAVES * 4 * 16 * 64 * 4;
+
+struct S1Block { f32x4 a, b[4]; };
+
+__global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+                                                                       const float* __restrict__ dy, float* __restrict__ slabs,
+                                                                       long slab_stride, int B, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float s1_red[];
+    // (wave index through readfirstlane: the compiler then keeps the reduction range, the image pointers and the gather
+    //  index in scalar registers -- as lane values they made the loop a divergent one with a vector load of idx[b] and a
+    //  full vmcnt(0) drain per group)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    const int nh = wave & 1, ks = wave >> 1;
+    const long G = (long)B * S1_GROUPS;
+    const int R = gridDim.x * 4, r = blockIdx.x * 4 + ks;
+    const int g0 = (int)(G * r / R), g1 = (int)(G * (r + 1) / R);
+
+    int boff[5], aoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int p = 8 * j + 4 * h, oy = p / 20, ox0 = p % 20;
+        boff[j] = ((2 * nh + (li >> 4)) * S1_H + oy * 4 + ((li >> 1) & 7)) * S1_H + ox0 * 4 + (li & 1) * 4;
+        aoff[j] = li * S1_SP + p;
+    }
+    f32x16 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    float bsum = 0.f;
+
+    S1Block ring[5];
+    auto ptrs = [&](int g, const float*& xb, const float*& dyb) {      // group g -> image b, row pair t (wave-uniform)
+        const int b = g / S1_GROUPS, t = g - b * S1_GROUPS;
+        const long img = idx ? idx[b] : (long)b;
+        xb = x + img * (S1_C * S1_H * S1_H) + t * (8 * S1_H);
+        dyb = dy + (long)b * (S1_OC * S1_SP) + t * 40;
+    };
+    auto issue = [&](S1Block& blk, int j, const float* xb, const float* dyb) {
+        blk.a = *reinterpret_cast<const f32x4*>(dyb + aoff[j]);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) blk.b[s] = *reinterpret_cast<const f32x4*>(xb + boff[j] + 4 * s);
+    };
+    if (g0 < g1) {
+        const float *xb, *dyb;
+        ptrs(g0, xb, dyb);
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            issue(ring[j], j, xb, dyb);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        for (int g = g0; g < g1; ++g) {
+            const float *xn, *dyn;
+            ptrs(g + 1 < g1 ? g + 1 : g1 - 1, xn, dyn);      // past the end: the last group again (never multiplied)
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                // one refill load behind every four MFMAs (a burst of five loads behind sixteen MFMAs left the matrix
+                // pipe idle while the wave sat in the address path's queue)
+                S1Block& blk = ring[j];
+                const f32x4 a = blk.a;
+                bsum += (a[0] + a[1]) + (a[2] + a[3]);
+                blk.a = *reinterpret_cast<const f32x4*>(dyn + aoff[j]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], blk.b[s][q], acc[q], 0, 0, 0);
+                    blk.b[s] = *reinterpret_cast<const f32x4*>(xn + boff[j] + 4 * s);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+    }
+    // fixed-order sum of the four sub-range partials of each channel half through LDS, one slab per workgroup
+    float* mine = s1_red + (size_t)wave * (4 * 16 * 64);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mine[(q * 16 + i) * 64 + lane] = acc[q][i];
+    __syncthreads();
+    float* slab = slabs + (long)blockIdx.x * slab_stride;
+    for (int e = threadIdx.x; e < 2 * 16 * 64; e += 64 * S1_WAVES) {
+        const int el = e & 63, ei = (e >> 6) & 15, enh = e >> 10;
+        f32x4 v;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sum += s1_red[(size_t)((2 * k + enh) * 4 + q) * (16 * 64) + ei * 64 + el];
+            v[q] = sum * scale;
+        }
+        const int eli = el & 31, oc = (ei & 3) + 8 * (ei >> 2) + 4 * (el >> 5);
+        const int n = ((2 * enh + (eli >> 4)) * 8 + ((eli >> 1) & 7)) * 8 + (eli & 1) * 4;
+        *reinterpret_cast<f32x4*>(slab + oc * S1_KC + n) = v;
+    }
+    // bias: lanes (li, h) of the nh == 0 waves hold the sums over their positions of dY[., li, .]
+    __syncthreads();
+    if (nh == 0) {
+        bsum += __shfl_xor(bsum, 32);
+        if (h == 0) s1_red[ks * 32 + li] = bsum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32)
+        slab[S1_OC * S1_KC + threadIdx.x] = ((s1_red[threadIdx.x] + s1_red[32 + threadIdx.x]) + s1_red[64 + threadIdx.x]) + s1_red[96 + threadIdx.x];
+}
 }  // namespace acktr

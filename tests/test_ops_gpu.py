@@ -158,3 +158,27 @@ def test_conv3_wgrad_stationary_accumulator(B):
     dw2 = torch.empty(32, 64, 3, 3, device='cuda')                   # separate buffers, no bias
     ops.conv2d_wgrad(x.cuda(), dy.cuda(), (32, 64, 3, 3), 1, dw2, None)
     assert torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize('B,gather', [(64, False), (70, True), (300, True), (1024, False)])
+def test_conv1_wgrad_stationary_accumulator(B, gather):
+    """conv_wgrad_sa.hpp, 8x8 stride-4 layer on 84x84x4 frames (B >= 64): ragged reduction ranges, gathered minibatch rows
+    out of a larger store, the /255 input scale, bias sums; against torch fp32 on the CPU, and run-to-run deterministic."""
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(B)
+    nstore = B + 17 if gather else B
+    store = torch.randint(0, 256, (nstore, 4, 84, 84), generator=g).float()
+    idx = torch.randperm(nstore, generator=g)[:B] if gather else None
+    x = store[idx] if gather else store
+    dy = torch.randn(B, 32, 20, 20, generator=g) * (torch.rand(B, 32, 20, 20, generator=g) < 0.6).float()
+    w = torch.zeros(32, 4, 8, 8, requires_grad=True)
+    bias = torch.zeros(32, requires_grad=True)
+    F.conv2d(x / 255.0, w, bias, stride=4).backward(dy)
+    flat = torch.full((32 * 256 + 32,), 3.0, device='cuda')          # dw and db adjacent, like the flat gradient buffer
+    dw, db = flat[:32 * 256].view(32, 4, 8, 8), flat[32 * 256:]
+    gi = idx.cuda() if gather else None
+    ops.conv2d_wgrad(store.cuda(), dy.cuda(), (32, 4, 8, 8), 4, dw, db, in_scale=1 / 255.0, gather_idx=gi)
+    assert rel(dw, w.grad) < 2e-5 and rel(db, bias.grad) < 2e-5
+    dw2 = torch.empty(32, 4, 8, 8, device='cuda')                    # separate buffers, no bias
+    ops.conv2d_wgrad(store.cuda(), dy.cuda(), (32, 4, 8, 8), 4, dw2, None, in_scale=1 / 255.0, gather_idx=gi)
+    assert torch.equal(dw2, dw)

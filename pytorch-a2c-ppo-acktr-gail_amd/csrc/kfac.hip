@@ -14,6 +14,7 @@
 #include <thread>
 
 #include "conv_ops.hpp"
+#include "kfac_cov_sa.hpp"
 #include "../../include/acktr_hip.h"
 
 namespace acktr {
@@ -49,6 +50,29 @@ static int cov_a_conv_t(const float* x, const int64_t* idx, int B, int C, float 
     if (rc) return rc;
     rc = launch_slab_reduce(out, ws, ns, (long)Kc * Kc, (long)Kc * Kc, alpha, 0, s);
     return rc ? rc : launch_symmetrize_lower(out, Kc, s);
+}
+
+// 8x8 stride-4 layer on 84x84x4 frames: stationary accumulators, one workgroup per CU (kfac_cov_sa.hpp)
+static int cov_a_conv1_sa(const float* x, const int64_t* idx, int B, float alpha, float* out, float* ws, long ws_floats,
+                          hipStream_t s) {
+    static const bool off = getenv("ACKTR_COV_A_TILE") != nullptr;          // tuning / comparison switch
+    hipDeviceProp_t prop;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+        cus = prop.multiProcessorCount;
+    }
+    int ns = B * C1A_GROUPS / 10;                       // at least ten row-pair groups per workgroup
+    if (ns > cus) ns = cus;
+    if (off || B < 64 || ns < 1 || ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * C1A_D * C1A_D) return -2;
+    hipLaunchKernelGGL(cov_a_conv1_sa_kernel, dim3(ns), dim3(256), 0, s, x, idx, ws, B);
+    ACKTR_LAUNCH_CHECK();
+    int rc = launch_slab_reduce(out, ws, ns, (long)C1A_D * C1A_D, (long)C1A_D * C1A_D, alpha, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(cov_a_conv1_mirror_kernel, dim3(C1A_D * C1A_D / 256), dim3(256), 0, s, out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
 }
 
 // stride-1 layer without a gather: both operands stream 4 padded positions per 16-byte load (zero patches at the pad)
@@ -293,6 +317,10 @@ extern "C" int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_i
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
     const long wf = workspace ? workspace_bytes / (long)sizeof(float) : 0;
+    if (H == 84 && W == 84 && KH == 8 && KW == 8 && S == 4 && C == C1A_C) {
+        const int rc = cov_a_conv1_sa(x, gather_idx, B, alpha, out, ws, wf, s);
+        if (rc != -2) return rc;
+    }
     if (H == 84 && W == 84 && KH == 8 && KW == 8 && S == 4) return cov_a_conv_t<8, 8, 4, 84, 84>(x, gather_idx, B, C, alpha, out, ws, wf, s);
     if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2) return cov_a_conv_t<4, 4, 2, 20, 20>(x, gather_idx, B, C, alpha, out, ws, wf, s);
     if (H == 9 && W == 9 && KH == 3 && KW == 3 && S == 1) {

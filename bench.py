@@ -312,12 +312,20 @@ def side_metrics(device):
                 torch.cuda.synchronize()
                 ms.append((time.perf_counter() - t0) * 1e3)
             res[ntraj] = (statistics.median(ms[2:]), len(loader))
+    t0 = time.perf_counter()
+    for _ in range(3):
+        torch.randperm(T * N)
+    rp_ms = (time.perf_counter() - t0) / 3 * 1e3
     out['gail'] = dict(workload='GAIL Discriminator 23->100->100->1 (configs[4]: obs 17, act 6, T=2048 x 1024 procs, batch 128)',
                        predict_reward_rollout_ms=round(min(pr[1:]), 3),
                        predict_reward_samples_per_s=round(T * N / (min(pr[1:]) * 1e-3), 1),
                        update_ms_4_trajectories=round(res[4][0], 3), update_batches_4_trajectories=res[4][1],
                        update_ms_64_trajectories=round(res[64][0], 3), update_batches_64_trajectories=res[64][1],
-                       us_per_discriminator_step=round(res[64][0] * 1e3 / res[64][1], 1))
+                       us_per_discriminator_step=round(res[64][0] * 1e3 / res[64][1], 1),
+                       # every update draws torch.randperm over all T*N rollout rows on the CPU first (reference
+                       # storage.py:119-123 through gail.py:60, same RNG stream): a fixed host cost per update
+                       cpu_randperm_ms_per_update=round(rp_ms, 3),
+                       us_per_discriminator_step_net_of_randperm=round(max(res[64][0] - rp_ms, 0.0) * 1e3 / res[64][1], 1))
     return out
 
 

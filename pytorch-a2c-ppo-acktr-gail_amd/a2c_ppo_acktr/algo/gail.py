@@ -217,7 +217,7 @@ class Discriminator(nn.Module):
         self.train()
         policy_data_generator = rollouts.feed_forward_generator(None, mini_batch_size=expert_loader.batch_size)
         losses = []
-        for expert_batch, policy_batch in zip(expert_loader, policy_data_generator):
+        for expert_batch, policy_batch in zip(_expert_batches(expert_loader), policy_data_generator):
             policy_state, policy_action = policy_batch[0], policy_batch[2]
             expert_state, expert_action = expert_batch
             expert_state = obsfilt(expert_state.numpy(), update=False)
@@ -293,6 +293,30 @@ class Discriminator(nn.Module):
         return out
 
 
+def _expert_batches(loader):
+    """Batches of `loader` -- the same rows in the same order from the same RNG draws.  For the loader main.py builds
+    (a plain single-process DataLoader over an ExpertDataset with the default collate, gail.py:57-66 / main.py:78-83)
+    the index batches are taken from the loader's own iterator and the rows come from ONE index_select on the
+    dataset's flat tensors, instead of `batch_size` __getitem__ calls and a default_collate per batch (400 us of the
+    ~1.1 ms a discriminator step took at batch 128).  Anything else is iterated as it is."""
+    from torch.utils.data import dataloader as _dl
+    ds = getattr(loader, 'dataset', None)
+    plain = (type(loader) is torch.utils.data.DataLoader and type(ds) is ExpertDataset and loader.num_workers == 0
+             and loader.collate_fn is _dl.default_collate and not loader.pin_memory and loader.batch_size is not None
+             and hasattr(_dl._BaseDataLoaderIter, '_next_index'))
+    if not plain:
+        for b in loader:
+            yield b
+        return
+    it = iter(loader)                       # the real iterator: its constructor and sampler draw from the CPU generator
+    while True:
+        try:
+            index = it._next_index()
+        except StopIteration:
+            return
+        yield ds.rows(index)
+
+
 class ExpertDataset(torch.utils.data.Dataset):
     """gail.py:113-166 -- the gail_experts on-disk format (gail_experts/convert_to_pytorch.py:28-48): a `torch.save`d
     dict {'states' [B,T,Do] f32, 'actions' [B,T,Da] f32, 'rewards' [B,T] f32, 'lengths' [B] i64}."""
@@ -325,6 +349,16 @@ class ExpertDataset(torch.utils.data.Dataset):
                 traj_idx += 1
             self.get_idx.append((traj_idx, i))
             i += 1
+
+        # flat [length, D] copies of the rows __getitem__ returns, for whole-batch fetches (`rows`)
+        ti = torch.tensor([a for a, _ in self.get_idx], dtype=torch.int64)
+        ii = torch.tensor([b for _, b in self.get_idx], dtype=torch.int64)
+        self._flat = (self.trajectories['states'][ti, ii].contiguous(), self.trajectories['actions'][ti, ii].contiguous())
+
+    def rows(self, index):
+        """what default_collate([self[i] for i in index]) returns, as two index_selects"""
+        ix = torch.as_tensor(index, dtype=torch.int64)
+        return [self._flat[0].index_select(0, ix), self._flat[1].index_select(0, ix)]
 
     def __len__(self):
         return self.length

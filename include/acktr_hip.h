@@ -291,6 +291,16 @@ int acktr_sym_eig_jacobi_block_f32(const acktr_jacobi_job* jobs, int count, floa
 int acktr_kfac_precondition_f32(const float* grad, const float* qt_g, const float* d_g, const float* qt_a,
                                 const float* d_a, int OUT, int IN, float damping, float* tmp1, float* tmp2,
                                 float* v_out, void* stream);
+/* reference kfac.py:216-227 for ALL layers of a step at once: the same four products as acktr_kfac_precondition_f32, with
+ * stage s of every layer in one grouped launch (4 launches, or 8 when some layers rule out 16-byte loads, instead of 4 per
+ * layer).  Each job needs its OWN tmp1 / tmp2 of OUT*IN floats (the layers run concurrently); v_out may not alias them. */
+typedef struct acktr_precond_job {
+    const float* grad; const float* qt_g; const float* d_g; const float* qt_a; const float* d_a;
+    float* tmp1; float* tmp2; float* v_out;
+    int OUT; int IN;
+} acktr_precond_job;
+int acktr_kfac_precondition_batched_f32(const acktr_precond_job* jobs, int count, float damping, void* stream);
+
 /* out[0] = vg_sum = lr^2 * <v, g>, out[1] = nu = min(1, sqrt(kl_clip / vg_sum)) -- kfac.py:229-234, on the
  * device (the reference syncs to the host here).  workspace: acktr_optim_workspace_bytes(). */
 int acktr_kfac_kl_clip_f32(const float* v, const float* g, long n, float lr, float kl_clip, float* out_vgsum_nu,

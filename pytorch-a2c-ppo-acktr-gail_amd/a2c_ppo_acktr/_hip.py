@@ -56,6 +56,12 @@ class JacobiJob(ctypes.Structure):
     _fields_ = [('a', c_p), ('d', c_p), ('qt', c_p), ('n', c_i)]
 
 
+class PrecondJob(ctypes.Structure):
+    """struct acktr_precond_job (include/acktr_hip.h)"""
+    _fields_ = [('grad', c_p), ('qt_g', c_p), ('d_g', c_p), ('qt_a', c_p), ('d_a', c_p), ('tmp1', c_p), ('tmp2', c_p),
+                ('v_out', c_p), ('OUT', c_i), ('IN', c_i)]
+
+
 class EigJob(ctypes.Structure):
     """struct acktr_eig_job (include/acktr_hip.h)"""
     _fields_ = [('a_inout_qt', c_p), ('d', c_p), ('n', c_i), ('reserved', c_i)]
@@ -115,6 +121,7 @@ _PROTOS = {
     'acktr_sym_eig_rocsolver_f32': (c_i, [c_p, c_i, c_p, c_p, c_p, c_f, c_p]),
     'acktr_sym_eig_rocsolver_multi_f32': (c_i, [ctypes.POINTER(EigJob), c_i, c_p, c_p, c_f, c_p]),
     'acktr_kfac_precondition_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
+    'acktr_kfac_precondition_batched_f32': (c_i, [ctypes.POINTER(PrecondJob), c_i, c_f, c_p]),
     'acktr_kfac_kl_clip_f32': (c_i, [c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p]),
     'acktr_gail_mix_concat_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
     'acktr_gail_bce_seed_f32': (c_i, [c_p, c_i, c_p, c_p, c_p, c_p]),

@@ -409,6 +409,24 @@ class KFACOptimizer(optim.Optimizer):
                         t_.copy_(buf[o:o + t_.numel()])
                         o += t_.numel()
 
+    def _precond_jobs(self, pol, gflat):
+        """ctypes job table of the batched preconditioner: per layer its gradient slot, eigenbases / eigenvalues, the slot
+        of the update vector, and two scratch slots of the same size (flat buffers laid out like the parameters)."""
+        key = (gflat.data_ptr(), self.v_flat.data_ptr(), self.qt_g.data_ptr(), self.qt_a.data_ptr())
+        if self.__dict__.get('_pj_key') != key:
+            if self.__dict__.get('_pj_tmp') is None or self._pj_tmp[0].numel() != gflat.numel():
+                self._pj_tmp = (torch.zeros_like(gflat), torch.zeros_like(gflat))
+            arr = (_hip.PrecondJob * len(self._mods))()
+            for i, m in enumerate(self._mods):
+                arr[i] = _hip.PrecondJob(
+                    _hip.dev_ptr(pol.grad_view(m.param, gflat)), ctypes.c_void_p(self.qt_g.data_ptr() + 4 * m.og),
+                    ctypes.c_void_p(self.d_g_flat.data_ptr() + 4 * m.dg_off), ctypes.c_void_p(self.qt_a.data_ptr() + 4 * m.oa),
+                    ctypes.c_void_p(self.d_a_flat.data_ptr() + 4 * m.da_off),
+                    _hip.dev_ptr(pol.grad_view(m.param, self._pj_tmp[0])), _hip.dev_ptr(pol.grad_view(m.param, self._pj_tmp[1])),
+                    _hip.dev_ptr(pol.grad_view(m.param, self.v_flat)), m.ng, m.na)
+            self._pj_arr, self._pj_key = arr, key
+        return self._pj_arr
+
     # ------------------------------------------------------------------ step (kfac.py:190-242)
     def step(self):
         pol = self.model
@@ -423,17 +441,11 @@ class KFACOptimizer(optim.Optimizer):
             la = self.damping + self.weight_decay
             if self.steps % self.Tf == 0:
                 self._eigendecompose()
-            for m in self._mods:
-                g = pol.grad_view(m.param, gflat)
-                v = pol.grad_view(m.param, self.v_flat)
-                with ops._Timed('kfac_precondition_%dx%d' % (m.ng, m.na), 4.0 * m.ng * m.na * (m.ng + m.na)):
-                    rc = L.acktr_kfac_precondition_f32(
-                        _hip.dev_ptr(g), ctypes.c_void_p(self.qt_g.data_ptr() + 4 * m.og),
-                        ctypes.c_void_p(self.d_g_flat.data_ptr() + 4 * m.dg_off),
-                        ctypes.c_void_p(self.qt_a.data_ptr() + 4 * m.oa),
-                        ctypes.c_void_p(self.d_a_flat.data_ptr() + 4 * m.da_off), m.ng, m.na, float(la),
-                        _hip.dev_ptr(self.tmp1), _hip.dev_ptr(self.tmp2), _hip.dev_ptr(v), stream)
-                _hip.check(rc, 'acktr_kfac_precondition_f32')
+            # kfac.py:216-227 for every layer: stage s of all layers in one grouped launch (acktr_kfac_precondition_batched_f32)
+            jobs = self._precond_jobs(pol, gflat)
+            with ops._Timed('kfac_precondition_all', sum(4.0 * m.ng * m.na * (m.ng + m.na) for m in self._mods)):
+                rc = L.acktr_kfac_precondition_batched_f32(jobs, len(self._mods), float(la), stream)
+            _hip.check(rc, 'acktr_kfac_precondition_batched_f32')
             ws = ops.workspace(dev, L.acktr_optim_workspace_bytes(), 'optim')
             rc = L.acktr_kfac_kl_clip_f32(_hip.dev_ptr(self.v_flat), _hip.dev_ptr(gflat), flat.numel(), float(self.lr),
                                           float(self.kl_clip), _hip.dev_ptr(self.nu_buf), _hip.dev_ptr(ws), stream)

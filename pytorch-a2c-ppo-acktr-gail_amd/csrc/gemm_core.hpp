@@ -133,6 +133,16 @@ struct EpiGatePrefetch : std::false_type {};
 template <class Epi>
 struct EpiGatePrefetch<Epi, std::enable_if_t<Epi::GATE_PREFETCH>> : std::true_type {};
 
+// Batched launches (ZBATCH): an operand may carry its own reduction length per blockIdx.z (zK()); others use the launch's K.
+template <class Op, class = void>
+struct OpZK {
+    __device__ static __forceinline__ int get(const Op&, int K) { return K; }
+};
+template <class Op>
+struct OpZK<Op, std::void_t<decltype(&Op::zK)>> {
+    __device__ static __forceinline__ int get(const Op& op, int) { return op.zK(); }
+};
+
 template <class Epi>
 struct EpiSym {
     __device__ static __forceinline__ bool skip(const Epi&, int, int, int) { return false; }
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_f32_kernel(const MOp mop, const
     const int kbeg = ZBATCH ? 0 : vz * kchunk;     // ZBATCH: z is a phase index the functors read themselves
     int kend = kbeg + kchunk;
     if (kend > K) kend = K;
+    if constexpr (ZBATCH) kend = OpZK<MOp>::get(mop, kend);
     const int nk = (kend - kbeg + GK - 1) / GK;
 
     f32x16 acc[TM][TN];

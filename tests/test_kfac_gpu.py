@@ -224,6 +224,32 @@ def test_precondition_vs_torch(OUT, IN):
     assert rel(v.cpu().numpy(), ref.numpy()) < 5e-5
 
 
+def test_precondition_batched_vs_torch():
+    """acktr_kfac_precondition_batched_f32: every layer shape class of the two policies in ONE call (16-byte and scalar
+    load groups, 1-column bias modules, 1- and 6-row heads, more jobs than one group holds) against torch fp64."""
+    from a2c_ppo_acktr import _hip
+    shapes = [(512, 1568), (64, 512), (32, 576), (32, 256), (1, 512), (6, 512), (512, 1), (64, 1), (32, 1), (6, 1), (1, 1),
+              (64, 64), (64, 11), (3, 64), (64, 17)] + [(8, 12)] * 6
+    g = torch.Generator().manual_seed(5)
+    keep, refs, outs = [], [], []
+    jobs = (_hip.PrecondJob * len(shapes))()
+    for i, (OUT, IN) in enumerate(shapes):
+        Ag, Aa = _psd(OUT, OUT + 5, g).double(), _psd(IN, IN + 5, g).double()
+        dg, Qg = torch.linalg.eigh(Ag)
+        da, Qa = torch.linalg.eigh(Aa)
+        G = torch.randn(OUT, IN, generator=g).double()
+        refs.append(Qg @ ((Qg.t() @ G @ Qa) / (dg.unsqueeze(1) * da.unsqueeze(0) + 0.01)) @ Qa.t())
+        dev = lambda x: x.float().contiguous().cuda()
+        ts = [dev(G), dev(Qg.t()), dev(dg), dev(Qa.t()), dev(da), torch.empty(OUT * IN, device='cuda'),
+              torch.empty(OUT * IN, device='cuda'), torch.empty(OUT, IN, device='cuda')]
+        keep.append(ts)
+        outs.append(ts[7])
+        jobs[i] = _hip.PrecondJob(*[_hip.dev_ptr(x) for x in ts], OUT, IN)
+    _hip.check(_hip.lib().acktr_kfac_precondition_batched_f32(jobs, len(shapes), 0.01, _hip.cur_stream()), 'precondition_batched')
+    for (OUT, IN), v, ref in zip(shapes, outs, refs):
+        assert rel(v.cpu().numpy(), ref.numpy()) < 5e-5, (OUT, IN)
+
+
 @pytest.mark.parametrize('ci', range(len(KFAC_CASES)))
 def test_acktr_update_vs_reference(ci):
     """Full A2C_ACKTR(acktr=True).update x3 (eigendecompositions at steps 0 and 2).  Losses, factors and

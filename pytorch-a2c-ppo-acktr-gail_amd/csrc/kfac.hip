@@ -76,6 +76,49 @@ static int cov_a_conv1_sa(const float* x, const int64_t* idx, int B, float alpha
     return 0;
 }
 
+// 4x4 stride-2 layer on 20x20x32 activations: stationary accumulators by channel-group pair (kfac_cov_sa.hpp)
+static int cov_a_conv2_sa(const float* x, int B, float alpha, float* out, float* ws, long ws_floats, hipStream_t s) {
+    static const bool off = getenv("ACKTR_COV_A_TILE") != nullptr;          // tuning / comparison switch
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+        cus = prop.multiProcessorCount;
+    }
+    if (off || B < 64 || cus < 20) return -2;
+    // workgroups per cross pair (16 tiles) and per diagonal pair (10 tiles): smallest worst-case wave time
+    int best_c = 1, best_d = 1;
+    long best = -1;
+    for (int nc = 1; 6 * nc + 4 <= cus; ++nc) {
+        const int nd = (cus - 6 * nc) / 4;
+        const long tc = (long)cdiv(B, 4 * nc) * 16, td = (long)cdiv(B, 4 * nd) * 10, t = tc > td ? tc : td;
+        if (best < 0 || t < best) { best = t; best_c = nc; best_d = nd; }
+    }
+    C2aPlan plan;
+    int p = 0, wg = 0;
+    for (int a = 0; a < 4; ++a)
+        for (int b = a; b < 4; ++b) {
+            plan.ga[p] = a; plan.gb[p] = b; plan.wg0[p] = wg;
+            wg += (a == b) ? best_d : best_c;
+            ++p;
+        }
+    plan.wg0[C2A_PAIRS] = wg;
+    if (ws_floats < (long)wg * C2A_SLAB) return -2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_a_conv2_sa_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, C2A_LDS_BYTES);
+        if (e != hipSuccess) { set_error("cov_a_conv2_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(cov_a_conv2_sa_kernel, dim3(wg), dim3(256), C2A_LDS_BYTES, s, x, ws, B, plan);
+    ACKTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL(c2a_reduce_kernel, dim3(64, C2A_PAIRS), dim3(256), 0, s, (const float*)ws, out, alpha, plan);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
 // stride-1 layer without a gather: both operands stream 4 padded positions per 16-byte load (zero patches at the pad)
 template <int KH, int KW, int H, int W, int OWP>
 static int cov_a_conv_pos_t(const float* x, int B, int C, float alpha, float* out, float* ws, long ws_floats,
@@ -323,6 +366,10 @@ extern "C" int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_i
         if (rc != -2) return rc;
     }
     if (H == 84 && W == 84 && KH == 8 && KW == 8 && S == 4) return cov_a_conv_t<8, 8, 4, 84, 84>(x, gather_idx, B, C, alpha, out, ws, wf, s);
+    if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2 && C == C2A_C && !gather_idx && (long)B * C2A_IMG < (1L << 31)) {
+        const int rc = cov_a_conv2_sa(x, B, alpha, out, ws, wf, s);
+        if (rc != -2) return rc;
+    }
     if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2) return cov_a_conv_t<4, 4, 2, 20, 20>(x, gather_idx, B, C, alpha, out, ws, wf, s);
     if (H == 9 && W == 9 && KH == 3 && KW == 3 && S == 1) {
         if (!gather_idx && (long)B * C * 81 < (1L << 31)) return cov_a_conv_pos_t<3, 3, 9, 9, 8>(x, B, C, alpha, out, ws, wf, s);

@@ -136,4 +136,183 @@ __global__ __launch_bounds__(256) void cov_a_conv1_mirror_kernel(float* out) {
     if (br > bc) out[e] = out[c * C1A_D + r];
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Same idea for the 4x4 stride-2 layer on 20x20x32 activations (NatureCNN's second convolution): A = alpha * P^T P,
+// P = patches [B*81, 512].  (Tile GEMM: 342 us = 40 TFLOP/s on the symmetric-half count.)
+//   * lane (li, h) stands for (channel 8g + li/4, ky = li%4) of channel group g (4 groups) and loads the four kx of its
+//     patch row with ONE 16-byte load (8-byte aligned: the stride is 2) -- float q belongs to block 4g + q, 16 blocks;
+//   * the 136 upper 32x32 tiles are cut by GROUP PAIR (ga <= gb): six cross pairs of 16 tiles, four diagonal pairs of 10.
+//     A workgroup works on ONE pair: its four waves run the same program (16 or 10 accumulators, two loads or one per
+//     k-pair step) on four different image ranges, add their partial sums through LDS in a fixed order and write one
+//     64 KB region slab.  The host deals workgroups to the ten pairs in proportion to their MFMA counts;
+//   * an image has 81 positions = ten blocks of 8 + one position: the eleventh block is a single k-pair step in which
+//     the upper k half is zeroed;  twelve virtual blocks per image walk a ring of three register slots, all offsets are
+//     compile-time constants selected by h;
+//   * c2a_reduce_kernel sums the region slabs in order, applies alpha and writes element (r, c) and its mirror.
+constexpr int C2A_HW = 400, C2A_C = 32, C2A_D = 512, C2A_IMG = C2A_C * C2A_HW, C2A_PAIRS = 10, C2A_SLAB = 16 * 1024;
+
+struct C2aPlan {
+    int wg0[C2A_PAIRS + 1];      // workgroups [wg0[p], wg0[p+1]) work on pair p; slab index == workgroup index
+    int ga[C2A_PAIRS], gb[C2A_PAIRS];
+};
+
+constexpr int c2a_pos_off(int p) { return (p / 9) * 40 + (p % 9) * 2; }
+__device__ __forceinline__ int c2a_tap(int g, int q, int l) { return (((8 * g + (l >> 2)) * 4 + (l & 3)) * 4) + q; }
+
+template <bool DIAG>
+struct C2aSlot;
+template <>
+struct C2aSlot<true> { f32x4 a[4]; };
+template <>
+struct C2aSlot<false> { f32x4 a[4], b[4]; };
+
+template <bool DIAG>
+__device__ __forceinline__ void c2a_wave(const float* __restrict__ x, float* __restrict__ slab, float* lds, int ga, int gb,
+                                         int img0, int img1, int lane, int wave) {
+    constexpr int NT = DIAG ? 10 : 16;
+    const int li = lane & 31, h = lane >> 5;
+    const int lbase = (li >> 2) * C2A_HW + (li & 3) * 20;
+    f32x16 acc[NT];
+#pragma unroll
+    for (int k = 0; k < NT; ++k)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
+    C2aSlot<DIAG> ring[3];
+    const float* xa = x + ga * (8 * C2A_HW);
+    const float* xb = x + gb * (8 * C2A_HW);
+    // virtual block vb (0..11) of the image at element offset io: block 11 does not exist, block 10 has one step
+    auto issue = [&](auto VB, C2aSlot<DIAG>& sl, long io) {
+        constexpr int vb = decltype(VB)::value;
+        if constexpr (vb <= 10) {
+#pragma unroll
+            for (int s = 0; s < (vb == 10 ? 1 : 4); ++s) {
+                const int p0 = 8 * vb + s, p1 = (vb == 10) ? 80 : 8 * vb + 4 + s;
+                const int off = lbase + (h ? c2a_pos_off(p1) : c2a_pos_off(p0));
+                sl.a[s] = *reinterpret_cast<const f32x4*>(xa + io + off);
+                if constexpr (!DIAG) sl.b[s] = *reinterpret_cast<const f32x4*>(xb + io + off);
+            }
+        }
+    };
+    auto consume = [&](auto VB, C2aSlot<DIAG>& sl) {
+        constexpr int vb = decltype(VB)::value;
+        if constexpr (vb <= 10) {
+#pragma unroll
+            for (int s = 0; s < (vb == 10 ? 1 : 4); ++s) {
+                f32x4 va = sl.a[s], vbv;
+                if constexpr (DIAG) vbv = va; else vbv = sl.b[s];
+                if constexpr (vb == 10) {                     // position 81.. of the image does not exist: zero k half 1
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { va[q] = h ? 0.f : va[q]; vbv[q] = h ? 0.f : vbv[q]; }
+                }
+                int k = 0;
+#pragma unroll
+                for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+                    for (int qj = (DIAG ? qi : 0); qj < 4; ++qj) {
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[qi], vbv[qj], acc[k], 0, 0, 0);
+                        ++k;
+                    }
+            }
+        }
+    };
+    auto step = [&](auto VB, long io_cur, long io_next) {       // consume virtual block vb, refill its slot with vb + 3
+        constexpr int vb = decltype(VB)::value;
+        C2aSlot<DIAG>& sl = ring[vb % 3];
+        consume(VB, sl);
+        if constexpr (vb + 3 < 12) issue(std::integral_constant<int, vb + 3>{}, sl, io_cur);
+        else issue(std::integral_constant<int, vb + 3 - 12>{}, sl, io_next);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (img0 < img1) {
+        const long io0 = (long)img0 * C2A_IMG;
+        issue(std::integral_constant<int, 0>{}, ring[0], io0);
+        issue(std::integral_constant<int, 1>{}, ring[1], io0);
+        issue(std::integral_constant<int, 2>{}, ring[2], io0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int img = img0; img < img1; ++img) {
+            const long io = (long)img * C2A_IMG, ion = (long)(img + 1 < img1 ? img + 1 : img1 - 1) * C2A_IMG;
+            step(std::integral_constant<int, 0>{}, io, ion);
+            step(std::integral_constant<int, 1>{}, io, ion);
+            step(std::integral_constant<int, 2>{}, io, ion);
+            step(std::integral_constant<int, 3>{}, io, ion);
+            step(std::integral_constant<int, 4>{}, io, ion);
+            step(std::integral_constant<int, 5>{}, io, ion);
+            step(std::integral_constant<int, 6>{}, io, ion);
+            step(std::integral_constant<int, 7>{}, io, ion);
+            step(std::integral_constant<int, 8>{}, io, ion);
+            step(std::integral_constant<int, 9>{}, io, ion);
+            step(std::integral_constant<int, 10>{}, io, ion);
+            step(std::integral_constant<int, 11>{}, io, ion);
+        }
+    }
+    // fixed-order sum of the four waves: (w0 + w2) + (w1 + w3), through 128 KB of LDS in two rounds
+    float* mine = lds + (size_t)(wave & 1) * (NT * 16 * 64);
+    if (wave >= 2) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) mine[(k * 16 + i) * 64 + lane] = acc[k][i];
+    }
+    __syncthreads();
+    if (wave < 2) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[k][i] += mine[(k * 16 + i) * 64 + lane];
+    }
+    __syncthreads();
+    if (wave == 1) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) lds[(k * 16 + i) * 64 + lane] = acc[k][i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) slab[(k * 16 + i) * 64 + lane] = acc[k][i] + lds[(k * 16 + i) * 64 + lane];
+    }
+}
+
+constexpr int C2A_LDS_BYTES = 2 * 16 * 16 * 64 * 4;     // two waves' accumulators
+
+__global__ __launch_bounds__(256) void cov_a_conv2_sa_kernel(const float* __restrict__ x, float* __restrict__ slabs, int B,
+                                                             const C2aPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float c2a_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < C2A_PAIRS; ++i) p += (int)blockIdx.x >= plan.wg0[i];
+    const int nw = plan.wg0[p + 1] - plan.wg0[p], w = (int)blockIdx.x - plan.wg0[p];
+    const int ranges = nw * 4, r = w * 4 + wave;
+    const int img0 = (int)((long)B * r / ranges), img1 = (int)((long)B * (r + 1) / ranges);
+    float* slab = slabs + (long)blockIdx.x * C2A_SLAB;
+    const int ga = plan.ga[p], gb = plan.gb[p];
+    if (ga == gb) c2a_wave<true>(x, slab, c2a_lds, ga, gb, img0, img1, lane, wave);
+    else c2a_wave<false>(x, slab, c2a_lds, ga, gb, img0, img1, lane, wave);
+}
+
+// out[r][c] = out[c][r] = alpha * sum over the pair's slabs, in slab order.  grid = (16 tiles * 4, C2A_PAIRS), block 256
+__global__ __launch_bounds__(256) void c2a_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, float alpha,
+                                                         const C2aPlan plan) {
+    const int p = blockIdx.y, ga = plan.ga[p], gb = plan.gb[p];
+    const int e = blockIdx.x * 256 + threadIdx.x;              // (tile slot k, register i, lane)
+    const int k = e >> 10, i = (e >> 6) & 15, lane = e & 63;
+    int qi = 0, qj = 0;
+    if (ga == gb) {                                            // k-th pair (qi <= qj), row-major
+        if (k >= 10) return;
+        int c = 0;
+        for (int a = 0; a < 4; ++a)
+            for (int b = a; b < 4; ++b) { if (c == k) { qi = a; qj = b; } ++c; }
+    } else { qi = k >> 2; qj = k & 3; }
+    float s = 0.f;
+    for (int w = plan.wg0[p]; w < plan.wg0[p + 1]; ++w) s += slabs[(long)w * C2A_SLAB + e];
+    s *= alpha;
+    const int row = c2a_tap(ga, qi, 4 * (lane >> 5) + (i & 3) + 8 * (i >> 2)), col = c2a_tap(gb, qj, lane & 31);
+    out[row * C2A_D + col] = s;
+    out[col * C2A_D + row] = s;
+}
+
 }  // namespace acktr

@@ -192,8 +192,8 @@ def side_metrics(device):
         out['roofline_kfac'] = dict(bound='mfma', kernel=dom[0], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
                                     unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
                                     avg_launch_ms=round(dom[1]['avg_ms'], 4), flop_per_launch=dom[1]['flops_per_call'],
-                                    flop_count='symmetric half R*D*(D+1) (SURVEY 8(d)); the kernel computes the upper '
-                                               'triangle of 128x128 tiles and mirrors it',
+                                    flop_count='symmetric half R*D*(D+1) (SURVEY 8(d)); the kernels compute the upper '
+                                               'triangle of 32x32 tiles (stationary accumulators) and mirror it',
                                     operators={k: dict(calls=v['calls'], avg_ms=round(v['avg_ms'], 4),
                                                        tflops=round(v['flops_per_call'] / (v['avg_ms'] * 1e-3) / 1e12, 2))
                                                for k, v in sorted(kprof.items(), key=lambda kv: -kv[1]['total_ms'])})

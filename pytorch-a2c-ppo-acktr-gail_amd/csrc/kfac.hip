@@ -76,8 +76,12 @@ static int cov_a_conv1_sa(const float* x, const int64_t* idx, int B, float alpha
     return 0;
 }
 
-// 4x4 stride-2 layer on 20x20x32 activations: stationary accumulators by channel-group pair (kfac_cov_sa.hpp)
-static int cov_a_conv2_sa(const float* x, int B, float alpha, float* out, float* ws, long ws_floats, hipStream_t s) {
+// 4x4 stride-2 layer on 20x20x32 and 3x3 stride-1 layer on 9x9x64 activations: stationary accumulators by channel-group
+// pair (kfac_cov_sa.hpp).  Workgroups are dealt to the pairs so that the slowest wave (images x tiles) is as short as
+// possible.
+template <class G>
+static int cov_a_sa(const float* x, int B, float alpha, float* out, float* ws, long ws_floats, hipStream_t s) {
+    using S = CovSa<G>;
     static const bool off = getenv("ACKTR_COV_A_TILE") != nullptr;          // tuning / comparison switch
     static int cus = 0;
     if (!cus) {
@@ -86,35 +90,35 @@ static int cov_a_conv2_sa(const float* x, int B, float alpha, float* out, float*
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
         cus = prop.multiProcessorCount;
     }
-    if (off || B < 64 || cus < 20) return -2;
-    // workgroups per cross pair (16 tiles) and per diagonal pair (10 tiles): smallest worst-case wave time
+    constexpr int NCROSS = S::PAIRS - G::NG, NDIAG = G::NG;
+    if (off || B < 64 || cus < NCROSS + NDIAG) return -2;
     int best_c = 1, best_d = 1;
     long best = -1;
-    for (int nc = 1; 6 * nc + 4 <= cus; ++nc) {
-        const int nd = (cus - 6 * nc) / 4;
-        const long tc = (long)cdiv(B, 4 * nc) * 16, td = (long)cdiv(B, 4 * nd) * 10, t = tc > td ? tc : td;
+    for (int nc = 1; NCROSS * nc + NDIAG <= cus; ++nc) {
+        const int nd = (cus - NCROSS * nc) / NDIAG;
+        const long tc = (long)cdiv(B, 4 * nc) * S::NT_CROSS, td = (long)cdiv(B, 4 * nd) * S::NT_DIAG, t = tc > td ? tc : td;
         if (best < 0 || t < best) { best = t; best_c = nc; best_d = nd; }
     }
-    C2aPlan plan;
+    CovPlan plan;
     int p = 0, wg = 0;
-    for (int a = 0; a < 4; ++a)
-        for (int b = a; b < 4; ++b) {
+    for (int a = 0; a < G::NG; ++a)
+        for (int b = a; b < G::NG; ++b) {
             plan.ga[p] = a; plan.gb[p] = b; plan.wg0[p] = wg;
             wg += (a == b) ? best_d : best_c;
             ++p;
         }
-    plan.wg0[C2A_PAIRS] = wg;
-    if (ws_floats < (long)wg * C2A_SLAB) return -2;
+    for (; p <= COVSA_MAX_PAIRS; ++p) plan.wg0[p] = wg;
+    if (ws_floats < (long)wg * S::SLAB) return -2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_a_conv2_sa_kernel),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, C2A_LDS_BYTES);
-        if (e != hipSuccess) { set_error("cov_a_conv2_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(cov_a_sa_kernel<G>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, S::LDS_BYTES);
+        if (e != hipSuccess) { set_error("cov_a_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(cov_a_conv2_sa_kernel, dim3(wg), dim3(256), C2A_LDS_BYTES, s, x, ws, B, plan);
+    hipLaunchKernelGGL(cov_a_sa_kernel<G>, dim3(wg), dim3(256), S::LDS_BYTES, s, x, ws, B, plan);
     ACKTR_LAUNCH_CHECK();
-    hipLaunchKernelGGL(c2a_reduce_kernel, dim3(64, C2A_PAIRS), dim3(256), 0, s, (const float*)ws, out, alpha, plan);
+    hipLaunchKernelGGL(cov_sa_reduce_kernel<G>, dim3(S::NT_CROSS * 4, S::PAIRS), dim3(256), 0, s, (const float*)ws, out, alpha, plan);
     ACKTR_LAUNCH_CHECK();
     return 0;
 }
@@ -366,8 +370,12 @@ extern "C" int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_i
         if (rc != -2) return rc;
     }
     if (H == 84 && W == 84 && KH == 8 && KW == 8 && S == 4) return cov_a_conv_t<8, 8, 4, 84, 84>(x, gather_idx, B, C, alpha, out, ws, wf, s);
-    if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2 && C == C2A_C && !gather_idx && (long)B * C2A_IMG < (1L << 31)) {
-        const int rc = cov_a_conv2_sa(x, B, alpha, out, ws, wf, s);
+    if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2 && C == 32 && !gather_idx && (long)B * CovGeom2::IMG < (1L << 31)) {
+        const int rc = cov_a_sa<CovGeom2>(x, B, alpha, out, ws, wf, s);
+        if (rc != -2) return rc;
+    }
+    if (H == 9 && W == 9 && KH == 3 && KW == 3 && S == 1 && C == 64 && !gather_idx && (long)B * CovGeom3::IMG < (1L << 31)) {
+        const int rc = cov_a_sa<CovGeom3>(x, B, alpha, out, ws, wf, s);
         if (rc != -2) return rc;
     }
     if (H == 20 && W == 20 && KH == 4 && KW == 4 && S == 2) return cov_a_conv_t<4, 4, 2, 20, 20>(x, gather_idx, B, C, alpha, out, ws, wf, s);

@@ -149,88 +149,117 @@ __global__ __launch_bounds__(256) void cov_a_conv1_mirror_kernel(float* out) {
 //     the upper k half is zeroed;  twelve virtual blocks per image walk a ring of three register slots, all offsets are
 //     compile-time constants selected by h;
 //   * c2a_reduce_kernel sums the region slabs in order, applies alpha and writes element (r, c) and its mirror.
-constexpr int C2A_HW = 400, C2A_C = 32, C2A_D = 512, C2A_IMG = C2A_C * C2A_HW, C2A_PAIRS = 10, C2A_SLAB = 16 * 1024;
-
-struct C2aPlan {
-    int wg0[C2A_PAIRS + 1];      // workgroups [wg0[p], wg0[p+1]) work on pair p; slab index == workgroup index
-    int ga[C2A_PAIRS], gb[C2A_PAIRS];
+// The 3x3 stride-1 layer on 9x9x64 activations (third convolution, 576 taps, 49 positions) runs the same program with
+// three kx per lane (one 12-byte load), six groups of 32 (channel, ky) rows and 21 group pairs of 9 / 6 tiles.
+struct CovGeom2 {      // 4x4 stride 2 on 20x20x32
+    static constexpr int NQ = 4, NG = 4, NPOS = 81, OW = 9, SY = 40, SX = 2, IMG = 32 * 400, D = 512, VBLOCKS = 12;
+    typedef f32x4 vec;
+    __device__ static __forceinline__ int lane_base(int, int li) { return (li >> 2) * 400 + (li & 3) * 20; }
+    __device__ static __forceinline__ long group_base(int g) { return (long)g * (8 * 400); }
+    __device__ static __forceinline__ int tap(int g, int q, int l) { return (((8 * g + (l >> 2)) * 4 + (l & 3)) * 4) + q; }
+};
+struct CovF3 { float v[3]; __device__ __forceinline__ float operator[](int i) const { return v[i]; } };
+struct CovGeom3 {      // 3x3 stride 1 on 9x9x64
+    static constexpr int NQ = 3, NG = 6, NPOS = 49, OW = 7, SY = 9, SX = 1, IMG = 64 * 81, D = 576, VBLOCKS = 9;
+    typedef CovF3 vec;
+    __device__ static __forceinline__ int lane_base(int g, int li) { const int pr = 32 * g + li; return (pr / 3) * 81 + (pr % 3) * 9; }
+    __device__ static __forceinline__ long group_base(int) { return 0; }
+    __device__ static __forceinline__ int tap(int g, int q, int l) { return (32 * g + l) * 3 + q; }
+};
+constexpr int COVSA_MAX_PAIRS = 21;
+template <class G> struct CovSa {
+    static constexpr int PAIRS = G::NG * (G::NG + 1) / 2;
+    static constexpr int NT_CROSS = G::NQ * G::NQ, NT_DIAG = G::NQ * (G::NQ + 1) / 2;
+    static constexpr int SLAB = NT_CROSS * 1024;                   // floats per region slab
+    static constexpr int LDS_BYTES = 2 * NT_CROSS * 1024 * 4;      // two waves' accumulators
+    static constexpr int NBLK = (G::NPOS + 7) / 8;                 // real 8-position blocks per image (the last: 1 position)
+    static_assert(G::NPOS % 8 == 1 && G::VBLOCKS % 3 == 0 && G::VBLOCKS >= NBLK, "position blocking");
+};
+struct CovPlan {
+    int wg0[COVSA_MAX_PAIRS + 1];      // workgroups [wg0[p], wg0[p+1]) work on pair p; slab index == workgroup index
+    int ga[COVSA_MAX_PAIRS], gb[COVSA_MAX_PAIRS];
 };
 
-constexpr int c2a_pos_off(int p) { return (p / 9) * 40 + (p % 9) * 2; }
-__device__ __forceinline__ int c2a_tap(int g, int q, int l) { return (((8 * g + (l >> 2)) * 4 + (l & 3)) * 4) + q; }
+template <class G> constexpr int cov_pos_off(int p) { return (p / G::OW) * G::SY + (p % G::OW) * G::SX; }
 
-template <bool DIAG>
-struct C2aSlot;
-template <>
-struct C2aSlot<true> { f32x4 a[4]; };
-template <>
-struct C2aSlot<false> { f32x4 a[4], b[4]; };
+template <class G, bool DIAG>
+struct CovSlot;
+template <class G>
+struct CovSlot<G, true> { typename G::vec a[4]; };
+template <class G>
+struct CovSlot<G, false> { typename G::vec a[4], b[4]; };
 
-template <bool DIAG>
-__device__ __forceinline__ void c2a_wave(const float* __restrict__ x, float* __restrict__ slab, float* lds, int ga, int gb,
-                                         int img0, int img1, int lane, int wave) {
-    constexpr int NT = DIAG ? 10 : 16;
+template <class G, bool DIAG>
+__device__ __forceinline__ void cov_sa_wave(const float* __restrict__ x, float* __restrict__ slab, float* lds, int ga, int gb,
+                                            int img0, int img1, int lane, int wave) {
+    using S = CovSa<G>;
+    using Vec = typename G::vec;
+    constexpr int NQ = G::NQ, NT = DIAG ? S::NT_DIAG : S::NT_CROSS, LAST = S::NBLK - 1, VB = G::VBLOCKS;
     const int li = lane & 31, h = lane >> 5;
-    const int lbase = (li >> 2) * C2A_HW + (li & 3) * 20;
+    const int lba = G::lane_base(ga, li), lbb = G::lane_base(gb, li);
     f32x16 acc[NT];
 #pragma unroll
     for (int k = 0; k < NT; ++k)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-    C2aSlot<DIAG> ring[3];
-    const float* xa = x + ga * (8 * C2A_HW);
-    const float* xb = x + gb * (8 * C2A_HW);
-    // virtual block vb (0..11) of the image at element offset io: block 11 does not exist, block 10 has one step
-    auto issue = [&](auto VB, C2aSlot<DIAG>& sl, long io) {
-        constexpr int vb = decltype(VB)::value;
-        if constexpr (vb <= 10) {
+    CovSlot<G, DIAG> ring[3];
+    const float* xa = x + G::group_base(ga);
+    const float* xb = x + G::group_base(gb);
+    // virtual block vb of the image at element offset io: blocks past LAST do not exist, block LAST has one step
+    auto issue = [&](auto VBc, CovSlot<G, DIAG>& sl, long io) {
+        constexpr int vb = decltype(VBc)::value;
+        if constexpr (vb <= LAST) {
 #pragma unroll
-            for (int s = 0; s < (vb == 10 ? 1 : 4); ++s) {
-                const int p0 = 8 * vb + s, p1 = (vb == 10) ? 80 : 8 * vb + 4 + s;
-                const int off = lbase + (h ? c2a_pos_off(p1) : c2a_pos_off(p0));
-                sl.a[s] = *reinterpret_cast<const f32x4*>(xa + io + off);
-                if constexpr (!DIAG) sl.b[s] = *reinterpret_cast<const f32x4*>(xb + io + off);
+            for (int s = 0; s < (vb == LAST ? 1 : 4); ++s) {
+                const int p0 = 8 * vb + s, p1 = (vb == LAST) ? G::NPOS - 1 : 8 * vb + 4 + s;
+                const int po = h ? cov_pos_off<G>(p1) : cov_pos_off<G>(p0);
+                sl.a[s] = *reinterpret_cast<const Vec*>(xa + io + lba + po);
+                if constexpr (!DIAG) sl.b[s] = *reinterpret_cast<const Vec*>(xb + io + lbb + po);
             }
         }
     };
-    auto consume = [&](auto VB, C2aSlot<DIAG>& sl) {
-        constexpr int vb = decltype(VB)::value;
-        if constexpr (vb <= 10) {
+    auto consume = [&](auto VBc, CovSlot<G, DIAG>& sl) {
+        constexpr int vb = decltype(VBc)::value;
+        if constexpr (vb <= LAST) {
 #pragma unroll
-            for (int s = 0; s < (vb == 10 ? 1 : 4); ++s) {
-                f32x4 va = sl.a[s], vbv;
-                if constexpr (DIAG) vbv = va; else vbv = sl.b[s];
-                if constexpr (vb == 10) {                     // position 81.. of the image does not exist: zero k half 1
+            for (int s = 0; s < (vb == LAST ? 1 : 4); ++s) {
+                float va[NQ], vbv[NQ];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { va[q] = h ? 0.f : va[q]; vbv[q] = h ? 0.f : vbv[q]; }
+                for (int q = 0; q < NQ; ++q) {
+                    va[q] = sl.a[s][q];
+                    if constexpr (DIAG) vbv[q] = va[q]; else vbv[q] = sl.b[s][q];
+                    if constexpr (vb == LAST) {               // positions past the image's last do not exist: zero k half 1
+                        va[q] = h ? 0.f : va[q];
+                        vbv[q] = h ? 0.f : vbv[q];
+                    }
                 }
                 int k = 0;
 #pragma unroll
-                for (int qi = 0; qi < 4; ++qi)
+                for (int qi = 0; qi < NQ; ++qi)
 #pragma unroll
-                    for (int qj = (DIAG ? qi : 0); qj < 4; ++qj) {
+                    for (int qj = (DIAG ? qi : 0); qj < NQ; ++qj) {
                         acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(va[qi], vbv[qj], acc[k], 0, 0, 0);
                         ++k;
                     }
             }
         }
     };
-    auto step = [&](auto VB, long io_cur, long io_next) {       // consume virtual block vb, refill its slot with vb + 3
-        constexpr int vb = decltype(VB)::value;
-        C2aSlot<DIAG>& sl = ring[vb % 3];
-        consume(VB, sl);
-        if constexpr (vb + 3 < 12) issue(std::integral_constant<int, vb + 3>{}, sl, io_cur);
-        else issue(std::integral_constant<int, vb + 3 - 12>{}, sl, io_next);
+    auto step = [&](auto VBc, long io_cur, long io_next) {     // consume virtual block vb, refill its slot with vb + 3
+        constexpr int vb = decltype(VBc)::value;
+        CovSlot<G, DIAG>& sl = ring[vb % 3];
+        consume(VBc, sl);
+        if constexpr (vb + 3 < VB) issue(std::integral_constant<int, vb + 3>{}, sl, io_cur);
+        else issue(std::integral_constant<int, vb + 3 - VB>{}, sl, io_next);
         __builtin_amdgcn_sched_barrier(0);
     };
     if (img0 < img1) {
-        const long io0 = (long)img0 * C2A_IMG;
+        const long io0 = (long)img0 * G::IMG;
         issue(std::integral_constant<int, 0>{}, ring[0], io0);
         issue(std::integral_constant<int, 1>{}, ring[1], io0);
         issue(std::integral_constant<int, 2>{}, ring[2], io0);
         __builtin_amdgcn_sched_barrier(0);
         for (int img = img0; img < img1; ++img) {
-            const long io = (long)img * C2A_IMG, ion = (long)(img + 1 < img1 ? img + 1 : img1 - 1) * C2A_IMG;
+            const long io = (long)img * G::IMG, ion = (long)(img + 1 < img1 ? img + 1 : img1 - 1) * G::IMG;
             step(std::integral_constant<int, 0>{}, io, ion);
             step(std::integral_constant<int, 1>{}, io, ion);
             step(std::integral_constant<int, 2>{}, io, ion);
@@ -240,13 +269,15 @@ __device__ __forceinline__ void c2a_wave(const float* __restrict__ x, float* __r
             step(std::integral_constant<int, 6>{}, io, ion);
             step(std::integral_constant<int, 7>{}, io, ion);
             step(std::integral_constant<int, 8>{}, io, ion);
-            step(std::integral_constant<int, 9>{}, io, ion);
-            step(std::integral_constant<int, 10>{}, io, ion);
-            step(std::integral_constant<int, 11>{}, io, ion);
+            if constexpr (VB > 9) {
+                step(std::integral_constant<int, 9 % VB>{}, io, ion);
+                step(std::integral_constant<int, 10 % VB>{}, io, ion);
+                step(std::integral_constant<int, 11 % VB>{}, io, ion);
+            }
         }
     }
-    // fixed-order sum of the four waves: (w0 + w2) + (w1 + w3), through 128 KB of LDS in two rounds
-    float* mine = lds + (size_t)(wave & 1) * (NT * 16 * 64);
+    // fixed-order sum of the four waves: (w0 + w2) + (w1 + w3), through LDS in two rounds
+    float* mine = lds + (size_t)(wave & 1) * (NT * 1024);
     if (wave >= 2) {
 #pragma unroll
         for (int k = 0; k < NT; ++k)
@@ -276,43 +307,45 @@ __device__ __forceinline__ void c2a_wave(const float* __restrict__ x, float* __r
     }
 }
 
-constexpr int C2A_LDS_BYTES = 2 * 16 * 16 * 64 * 4;     // two waves' accumulators
-
-__global__ __launch_bounds__(256) void cov_a_conv2_sa_kernel(const float* __restrict__ x, float* __restrict__ slabs, int B,
-                                                             const C2aPlan plan) {
-    extern __shared__ __attribute__((aligned(16))) float c2a_lds[];
+template <class G>
+__global__ __launch_bounds__(256) void cov_a_sa_kernel(const float* __restrict__ x, float* __restrict__ slabs, int B,
+                                                       const CovPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float cov_sa_lds[];
+    using S = CovSa<G>;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int p = 0;
 #pragma unroll
-    for (int i = 1; i < C2A_PAIRS; ++i) p += (int)blockIdx.x >= plan.wg0[i];
+    for (int i = 1; i < S::PAIRS; ++i) p += (int)blockIdx.x >= plan.wg0[i];
     const int nw = plan.wg0[p + 1] - plan.wg0[p], w = (int)blockIdx.x - plan.wg0[p];
     const int ranges = nw * 4, r = w * 4 + wave;
     const int img0 = (int)((long)B * r / ranges), img1 = (int)((long)B * (r + 1) / ranges);
-    float* slab = slabs + (long)blockIdx.x * C2A_SLAB;
+    float* slab = slabs + (long)blockIdx.x * S::SLAB;
     const int ga = plan.ga[p], gb = plan.gb[p];
-    if (ga == gb) c2a_wave<true>(x, slab, c2a_lds, ga, gb, img0, img1, lane, wave);
-    else c2a_wave<false>(x, slab, c2a_lds, ga, gb, img0, img1, lane, wave);
+    if (ga == gb) cov_sa_wave<G, true>(x, slab, cov_sa_lds, ga, gb, img0, img1, lane, wave);
+    else cov_sa_wave<G, false>(x, slab, cov_sa_lds, ga, gb, img0, img1, lane, wave);
 }
 
-// out[r][c] = out[c][r] = alpha * sum over the pair's slabs, in slab order.  grid = (16 tiles * 4, C2A_PAIRS), block 256
-__global__ __launch_bounds__(256) void c2a_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, float alpha,
-                                                         const C2aPlan plan) {
+// out[r][c] = out[c][r] = alpha * sum over the pair's slabs, in slab order.  grid = (NT_CROSS * 4, PAIRS), block 256
+template <class G>
+__global__ __launch_bounds__(256) void cov_sa_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out, float alpha,
+                                                            const CovPlan plan) {
+    using S = CovSa<G>;
     const int p = blockIdx.y, ga = plan.ga[p], gb = plan.gb[p];
     const int e = blockIdx.x * 256 + threadIdx.x;              // (tile slot k, register i, lane)
     const int k = e >> 10, i = (e >> 6) & 15, lane = e & 63;
     int qi = 0, qj = 0;
     if (ga == gb) {                                            // k-th pair (qi <= qj), row-major
-        if (k >= 10) return;
+        if (k >= S::NT_DIAG) return;
         int c = 0;
-        for (int a = 0; a < 4; ++a)
-            for (int b = a; b < 4; ++b) { if (c == k) { qi = a; qj = b; } ++c; }
-    } else { qi = k >> 2; qj = k & 3; }
+        for (int a = 0; a < G::NQ; ++a)
+            for (int b = a; b < G::NQ; ++b) { if (c == k) { qi = a; qj = b; } ++c; }
+    } else { qi = k / G::NQ; qj = k % G::NQ; }
     float s = 0.f;
-    for (int w = plan.wg0[p]; w < plan.wg0[p + 1]; ++w) s += slabs[(long)w * C2A_SLAB + e];
+    for (int w = plan.wg0[p]; w < plan.wg0[p + 1]; ++w) s += slabs[(long)w * S::SLAB + e];
     s *= alpha;
-    const int row = c2a_tap(ga, qi, 4 * (lane >> 5) + (i & 3) + 8 * (i >> 2)), col = c2a_tap(gb, qj, lane & 31);
-    out[row * C2A_D + col] = s;
-    out[col * C2A_D + row] = s;
+    const int row = G::tap(ga, qi, 4 * (lane >> 5) + (i & 3) + 8 * (i >> 2)), col = G::tap(gb, qj, lane & 31);
+    out[row * G::D + col] = s;
+    out[col * G::D + row] = s;
 }
 
 }  // namespace acktr

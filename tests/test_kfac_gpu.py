@@ -20,10 +20,10 @@ def rel(a, b):
     return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30))
 
 
-# (B >= 64 on the 84x84x4 and 20x20x32 layers runs the stationary-accumulator kernels of kfac_cov_sa.hpp, ragged ranges
+# (B >= 64 on the 84x84x4, 20x20x32 and 9x9x64 layers runs the stationary-accumulator kernels of kfac_cov_sa.hpp, ragged ranges
 # at 70, 300 and 333)
 @pytest.mark.parametrize('H,K,S,C,B', [(84, 8, 4, 4, 7), (20, 4, 2, 32, 9), (9, 3, 1, 64, 40), (84, 8, 4, 4, 70), (84, 8, 4, 4, 300),
-                                       (20, 4, 2, 32, 70), (20, 4, 2, 32, 333)])
+                                       (20, 4, 2, 32, 70), (20, 4, 2, 32, 333), (9, 3, 1, 64, 70), (9, 3, 1, 64, 333)])
 def test_cov_a_conv_vs_oracle(H, K, S, C, B):
     from a2c_ppo_acktr import _hip, ops
     g = torch.Generator().manual_seed(H + B)

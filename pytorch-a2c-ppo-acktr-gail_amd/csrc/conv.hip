@@ -155,6 +155,29 @@ static int conv1_wgrad_sa(const float* x, const int64_t* idx, const float* dy, f
     return launch_slab_reduce(db, ws + wk, ns, S1_OC, slab, 1.f, 0, s);
 }
 
+// 4x4 stride-2 layer on 20x20x32 activations with OC == 64: stationary accumulators (conv_wgrad_sa.hpp)
+static bool sa2_wgrad_ok(int geom, int C, int OC, int B, const int64_t* idx) {
+    static const bool off = getenv("ACKTR_CONV2_WGRAD_TILE") != nullptr;     // tuning / comparison switch
+    return !off && geom == GEOM_4S2 && C == S2_C && OC == S2_OC && B >= 64 && !idx && (long)B * S2_IMG < (1L << 31);
+}
+static int sa2_wgrad_slabs(int B) {
+    const int cus = sw_num_cus();
+    const int by_work = B / 2;                         // at least two images per workgroup
+    return by_work < cus ? (by_work < 1 ? 1 : by_work) : cus;
+}
+static int conv2_wgrad_sa(const float* x, const float* dy, float* dw, float* db, int B, float scale, float* ws, long ws_floats,
+                          hipStream_t s) {
+    const long wk = (long)S2_OC * S2_KC, slab = wk + S2_OC;
+    const int ns = sa2_wgrad_slabs(B);
+    if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
+    hipLaunchKernelGGL(conv2_wgrad_sa_kernel, dim3(ns), dim3(64 * S2_WAVES), 0, s, x, dy, ws, slab, B, scale);
+    ACKTR_LAUNCH_CHECK();
+    if (db == dw + wk) return launch_slab_reduce(dw, ws, ns, wk + S2_OC, slab, 1.f, 0, s);
+    int rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
+    if (rc || !db) return rc;
+    return launch_slab_reduce(db, ws + wk, ns, S2_OC, slab, 1.f, 0, s);
+}
+
 // dgrad weights re-packed once per call into dense per-phase matrices Wp[phase][c][k], k = (oc, a, a'), rows padded
 // to a multiple of 4: the GEMM's M operand then streams 16-byte rows instead of gathering 4-byte taps that sit
 // KH*KW*C floats apart (one cache line per lane).
@@ -342,6 +365,7 @@ extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, i
     int ns = pick_slices((long)cdiv(OC, BM) * cdiv(Kc, 128), (long)B * OH * OWP, 1024);
     if (sa_wgrad_ok(geom_of(H, W, KH, KW, S), C, OC, nullptr) && sa_wgrad_slabs(B) > ns) ns = sa_wgrad_slabs(B);
     if (sa1_wgrad_ok(geom_of(H, W, KH, KW, S), C, OC, B) && sa1_wgrad_slabs(B) > ns) ns = sa1_wgrad_slabs(B);
+    if (sa2_wgrad_ok(geom_of(H, W, KH, KW, S), C, OC, B, nullptr) && sa2_wgrad_slabs(B) > ns) ns = sa2_wgrad_slabs(B);
     return (long)(ns + SLAB_GROUP_EXTRA) * wgrad_slab_floats(OC, Kc) * (long)sizeof(float);
 }
 
@@ -360,6 +384,10 @@ extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx,
               : conv_wgrad_t<KH_, KW_, S_, H_, W_, 64, 2, 2>(x, gather_idx, dy, dw, db, B, C, OC, in_scale, ws, wf, s))
     if (sa1_wgrad_ok(geom, C, OC, B)) {
         const int rc = conv1_wgrad_sa(x, gather_idx, dy, dw, db, B, in_scale, ws, wf, s);
+        if (rc != -2) return rc;
+    }
+    if (sa2_wgrad_ok(geom, C, OC, B, gather_idx)) {
+        const int rc = conv2_wgrad_sa(x, dy, dw, db, B, in_scale, ws, wf, s);
         if (rc != -2) return rc;
     }
     if (geom == GEOM_8S4) return WG(8, 8, 4, 84, 84);

@@ -249,4 +249,129 @@ __global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const flo
     if (threadIdx.x < 32)
         slab[S1_OC * S1_KC + threadIdx.x] = ((s1_red[threadIdx.x] + s1_red[32 + threadIdx.x]) + s1_red[64 + threadIdx.x]) + s1_red[96 + threadIdx.x];
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Stationary-accumulator weight gradient of the 4x4 stride-2 layer on 20x20x32 activations (reference model.py:177, its
+// autograd backward):  dW[oc, (c,ky,kx)] = scale * sum_{b,p} dY[b,oc,p] * X[b,c,2oy+ky,2ox+kx],  db[oc] = sum dY.
+// Same construction as conv1_wgrad_sa_kernel; what differs:
+//   * 64 oc = two MFMA row blocks, 512 taps = four channel groups of 8: a wave owns one group as four interleaved
+//     column blocks (kx = the four floats of one 16-byte load, 8-byte aligned) x two row blocks = eight accumulators;
+//   * 81 positions per image = ten blocks of 8 + one position (a single k-pair step whose upper k half is zeroed in A);
+//     twelve virtual blocks walk a ring of three register slots, all offsets compile-time constants selected by h;
+//     A is one 16-byte load (4-byte aligned: rows of 81 floats) per row block and slot, a single float in the last block;
+//   * eight waves = 4 groups x 2 image sub-ranges; the second sub-range's partial sums go through LDS (128 KB), the first
+//     adds them and writes the slab rows with 16-byte stores (a lane's four kx are adjacent).
+constexpr int S2_C = 32, S2_HW = 400, S2_OC = 64, S2_SP = 81, S2_KC = 512, S2_WAVES = 4, S2_IMG = S2_C * S2_HW;
+constexpr int s2_pos_off(int p) { return (p / 9) * 40 + (p % 9) * 2; }
+
+struct S2Slot { f32x4 b[4]; f32x4 a[2]; };
+
+__global__ __launch_bounds__(64 * S2_WAVES) void conv2_wgrad_sa_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       float* __restrict__ slabs, long slab_stride, int B,
+                                                                       float scale) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    const int g = wave;
+    const int img0 = (int)((long)B * blockIdx.x / gridDim.x), img1 = (int)((long)B * (blockIdx.x + 1) / gridDim.x);
+    const int lbase = (8 * g + (li >> 2)) * S2_HW + (li & 3) * 20;     // channel, ky of this lane
+    const int abase = li * S2_SP;                                      // dY row of this lane (row block 0; +32 rows for 1)
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mb][q][i] = 0.f;
+    float bsum[2] = {0.f, 0.f};
+    S2Slot ring[3];
+    auto issue = [&](auto VBc, S2Slot& sl, int img) {
+        constexpr int vb = decltype(VBc)::value;
+        const float* xi = x + (long)img * S2_IMG;
+        const float* di = dy + (long)img * (S2_OC * S2_SP);
+        if constexpr (vb < 10) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int po = h ? s2_pos_off(8 * vb + 4 + s) : s2_pos_off(8 * vb + s);
+                sl.b[s] = *reinterpret_cast<const f32x4*>(xi + lbase + po);
+            }
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                struct __attribute__((packed, aligned(4))) U4 { f32x4 v; };
+                sl.a[mb] = reinterpret_cast<const U4*>(di + abase + mb * (32 * S2_SP) + 8 * vb + 4 * h)->v;
+            }
+        } else if constexpr (vb == 10) {
+            sl.b[0] = *reinterpret_cast<const f32x4*>(xi + lbase + s2_pos_off(80));
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) sl.a[mb][0] = di[abase + mb * (32 * S2_SP) + 80];
+        }
+    };
+    auto consume = [&](auto VBc, S2Slot& sl) {
+        constexpr int vb = decltype(VBc)::value;
+        if constexpr (vb <= 10) {
+#pragma unroll
+            for (int s = 0; s < (vb == 10 ? 1 : 4); ++s) {
+                float a0 = sl.a[0][s], a1 = sl.a[1][s];
+                if constexpr (vb == 10) { a0 = h ? 0.f : a0; a1 = h ? 0.f : a1; }     // position 81 does not exist
+                bsum[0] += a0;
+                bsum[1] += a1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    acc[0][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, sl.b[s][q], acc[0][q], 0, 0, 0);
+                    acc[1][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, sl.b[s][q], acc[1][q], 0, 0, 0);
+                }
+            }
+        }
+    };
+    auto step = [&](auto VBc, int img, int imgn) {
+        constexpr int vb = decltype(VBc)::value;
+        S2Slot& sl = ring[vb % 3];
+        consume(VBc, sl);
+        if constexpr (vb + 3 < 12) issue(std::integral_constant<int, vb + 3>{}, sl, img);
+        else issue(std::integral_constant<int, vb + 3 - 12>{}, sl, imgn);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    if (img0 < img1) {
+        issue(std::integral_constant<int, 0>{}, ring[0], img0);
+        issue(std::integral_constant<int, 1>{}, ring[1], img0);
+        issue(std::integral_constant<int, 2>{}, ring[2], img0);
+        __builtin_amdgcn_sched_barrier(0);
+        for (int img = img0; img < img1; ++img) {
+            const int imgn = img + 1 < img1 ? img + 1 : img1 - 1;     // past the end: the last image again (never multiplied)
+            step(std::integral_constant<int, 0>{}, img, imgn);
+            step(std::integral_constant<int, 1>{}, img, imgn);
+            step(std::integral_constant<int, 2>{}, img, imgn);
+            step(std::integral_constant<int, 3>{}, img, imgn);
+            step(std::integral_constant<int, 4>{}, img, imgn);
+            step(std::integral_constant<int, 5>{}, img, imgn);
+            step(std::integral_constant<int, 6>{}, img, imgn);
+            step(std::integral_constant<int, 7>{}, img, imgn);
+            step(std::integral_constant<int, 8>{}, img, imgn);
+            step(std::integral_constant<int, 9>{}, img, imgn);
+            step(std::integral_constant<int, 10>{}, img, imgn);
+            step(std::integral_constant<int, 11>{}, img, imgn);
+        }
+    }
+    // each wave writes its group's 128 columns of the slab: a lane's four kx are adjacent -> 16-byte stores
+    float* slab = slabs + (long)blockIdx.x * slab_stride;
+    const int col = ((8 * g + (li >> 2)) * 4 + (li & 3)) * 4;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int oc = 32 * mb + 4 * h + (i & 3) + 8 * (i >> 2);
+            f32x4 v;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = acc[mb][q][i] * scale;
+            *reinterpret_cast<f32x4*>(slab + oc * S2_KC + col) = v;
+        }
+    if (g == 0) {                                    // every group saw all of dY: group 0 reports the bias sums
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            float v = bsum[mb];
+            v += __shfl_xor(v, 32);
+            if (h == 0) slab[S2_OC * S2_KC + 32 * mb + li] = v;
+        }
+    }
+}
+
 }  // namespace acktr

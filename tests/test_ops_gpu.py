@@ -182,3 +182,23 @@ def test_conv1_wgrad_stationary_accumulator(B, gather):
     dw2 = torch.empty(32, 4, 8, 8, device='cuda')                    # separate buffers, no bias
     ops.conv2d_wgrad(store.cuda(), dy.cuda(), (32, 4, 8, 8), 4, dw2, None, in_scale=1 / 255.0, gather_idx=gi)
     assert torch.equal(dw2, dw)
+
+
+@pytest.mark.parametrize('B', [64, 71, 300, 1024])
+def test_conv2_wgrad_stationary_accumulator(B):
+    """conv_wgrad_sa.hpp, 4x4 stride-2 layer on 20x20x32 activations (B >= 64): ragged image ranges, the single-position
+    eleventh block of every image, bias sums, the last image's tail; against torch fp32 on the CPU."""
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(B + 1)
+    x = torch.relu(torch.rand(B, 32, 20, 20, generator=g) - 0.3)
+    dy = torch.randn(B, 64, 9, 9, generator=g) * (torch.rand(B, 64, 9, 9, generator=g) < 0.6).float()
+    w = torch.zeros(64, 32, 4, 4, requires_grad=True)
+    bias = torch.zeros(64, requires_grad=True)
+    F.conv2d(x, w, bias, stride=2).backward(dy)
+    flat = torch.full((64 * 512 + 64,), 3.0, device='cuda')          # dw and db adjacent, like the flat gradient buffer
+    dw, db = flat[:64 * 512].view(64, 32, 4, 4), flat[64 * 512:]
+    ops.conv2d_wgrad(x.cuda(), dy.cuda(), (64, 32, 4, 4), 2, dw, db)
+    assert rel(dw, w.grad) < 2e-5 and rel(db, bias.grad) < 2e-5
+    dw2 = torch.empty(64, 32, 4, 4, device='cuda')                   # separate buffers, no bias
+    ops.conv2d_wgrad(x.cuda(), dy.cuda(), (64, 32, 4, 4), 2, dw2, None)
+    assert torch.equal(dw2, dw)

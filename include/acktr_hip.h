@@ -358,6 +358,14 @@ typedef struct acktr_mlp_step_args {
     float clip, value_coef, entropy_coef, inv_batch;
     int use_clipped_value_loss;
     float* loss_acc;            /* nullable */
+    /* optional optimiser tail (all null / 0: off): clip_grad_norm_(opt_max_norm) + Adam over the flat buffers the g*
+     * pointers above point into, in the same launch, with the arithmetic and device-side {lr, beta1, beta2, eps} / step
+     * counter of acktr_clip_adam_dev_f32 (the counter is incremented here).  opt_max_norm <= 0: no clipping. */
+    float *opt_params, *opt_grads, *opt_exp_avg, *opt_exp_avg_sq;
+    long opt_n;
+    float opt_max_norm;
+    const float* opt_hyper_dev;
+    int* opt_step_dev;
 } acktr_mlp_step_args;
 int acktr_mlp_fused_step_supported(int B, int IN, int H, int A);
 int acktr_mlp_fused_step_f32(const acktr_mlp_step_args* args, void* stream);

@@ -42,7 +42,9 @@ class MlpStepArgs(ctypes.Structure):
                 [('B', c_i), ('IN', c_i), ('H', c_i), ('A', c_i), ('algo', c_i)] +
                 [(n, c_p) for n in ('actions', 'old_logp', 'old_values', 'returns', 'adv')] +
                 [('clip', c_f), ('value_coef', c_f), ('entropy_coef', c_f), ('inv_batch', c_f),
-                 ('use_clipped_value_loss', c_i), ('loss_acc', c_p)])
+                 ('use_clipped_value_loss', c_i), ('loss_acc', c_p)] +
+                [(n, c_p) for n in ('opt_params', 'opt_grads', 'opt_exp_avg', 'opt_exp_avg_sq')] +
+                [('opt_n', c_l), ('opt_max_norm', c_f), ('opt_hyper_dev', c_p), ('opt_step_dev', c_p)])
 
 
 class ConvPackJob(ctypes.Structure):

@@ -101,8 +101,9 @@ class PPO():
         self._seen_key = None
 
     # one minibatch step = ppo.py:57-84
-    def _fwd_bwd(self, b, phase=None):
-        """phase None: forward, loss and the whole backward.  Data-parallel NatureCNN runs split it in two so that the
+    def _fwd_bwd(self, b, phase=None, with_optimizer=False):
+        """phase None: forward, loss and the whole backward.  Returns True when the optimiser step ran too
+        (`with_optimizer` and the one-launch MLP step: clip + Adam are the tail of that launch).  Data-parallel NatureCNN runs split it in two so that the
         all-reduce of the late gradient bucket (conv3, FC, head: 97 % of the bytes) overlaps with the rest of the
         backward: phase 1 = forward, loss, backward down to conv3's weights; phase 2 = the remaining backward."""
         ac = self.actor_critic
@@ -115,8 +116,9 @@ class PPO():
                                   b['inv_batch'], old_logp=b['old_logp'], old_values=b['old_values'],
                                   returns=b['returns'], adv=b['adv'], clip=self.clip_param,
                                   value_coef=self.value_loss_coef, entropy_coef=self.entropy_coef,
-                                  use_clipped_value_loss=self.use_clipped_value_loss)
-            return
+                                  use_clipped_value_loss=self.use_clipped_value_loss,
+                                  adam=self.optimizer if with_optimizer else None, max_grad_norm=self.max_grad_norm)
+            return with_optimizer
         fuse_head = b.get('hxs') is None and engine.head_step_ok(ac, nrows)
         acts = engine.forward(ac, b['obs'], gather_idx=b['idx'], rnn_hxs=b.get('hxs'), masks=b.get('masks'),
                               head=not fuse_head)
@@ -127,6 +129,14 @@ class PPO():
             entropy_coef=self.entropy_coef, use_clipped_value_loss=self.use_clipped_value_loss)
         engine.backward(ac, acts, ac.flat_grads, phase=phase)
         self._acts = acts if phase == 1 else None
+        return False
+
+    def _step(self, b, capturing=False):
+        """one single-process minibatch step: forward, loss, backward, clip + Adam (ppo.py:57-84)"""
+        if self._fwd_bwd(b, with_optimizer=True):
+            self.optimizer.step_count += 1
+        else:
+            self.optimizer.step(self.max_grad_norm, capturing=capturing)
 
     def _dp_step(self, b, split, graphs):
         """One data-parallel minibatch step: (phase 1) -> start all-reduce of grads[split:] -> (phase 2) -> all-reduce
@@ -187,8 +197,7 @@ class PPO():
                 g2 = g3 = None
                 if not self.dp.active:
                     with torch.cuda.graph(g1):
-                        self._fwd_bwd(b)
-                        self.optimizer.step(self.max_grad_norm, capturing=True)
+                        self._step(b, capturing=True)
                         self.optimizer.step_count -= 1
                 else:                                       # the all-reduce sits between the two graphs
                     with torch.cuda.graph(g1):
@@ -208,8 +217,7 @@ class PPO():
                         self._graphs[0].replay()
                         self.optimizer.step_count += 1
                     else:
-                        self._fwd_bwd(b)
-                        self.optimizer.step(self.max_grad_norm)                        # ppo.py:82-84
+                        self._step(b)                                                  # ppo.py:57-84
             self.dp.all_reduce_sum_(self._loss_acc)
             num_updates = self.ppo_epoch * self.num_mini_batch
             vl, al, en = (self._loss_acc / num_updates).tolist()                    # the only host sync

@@ -456,8 +456,10 @@ def mlp_fused_ok(policy, B):
 
 def mlp_fused_step(policy, obs, gather_idx, B, algo, actions, loss_acc, inv_batch, old_logp=None, old_values=None,
                    returns=None, adv=None, clip=0.0, value_coef=0.0, entropy_coef=0.0, use_clipped_value_loss=True,
-                   gflat=None):
-    """forward + loss + backward of one minibatch in ONE launch; gradients overwrite `gflat` (default flat_grads)."""
+                   gflat=None, adam=None, max_grad_norm=None):
+    """forward + loss + backward of one minibatch in ONE launch; gradients overwrite `gflat` (default flat_grads).
+    `adam` (a ppo._FlatAdam whose device state is prepared): clip_grad_norm_(max_grad_norm) + the Adam step run in the
+    same launch (the device step counter is incremented by the kernel; the caller keeps `step_count` in step)."""
     L = mlp_layer_params(policy)
     gflat = policy.flat_grads if gflat is None else gflat
     dev = obs.device
@@ -483,6 +485,15 @@ def mlp_fused_step(policy, obs, gather_idx, B, algo, actions, loss_acc, inv_batc
     a.clip, a.value_coef, a.entropy_coef, a.inv_batch = clip, value_coef, entropy_coef, inv_batch
     a.use_clipped_value_loss = 1 if use_clipped_value_loss else 0
     a.loss_acc = p(loss_acc)
+    if adam is not None:
+        if gflat is not policy.flat_grads:
+            raise RuntimeError('the fused optimiser tail works on the policy\'s own flat gradient buffer')
+        a.opt_params, a.opt_grads = p(policy.flat_params), p(gflat)
+        a.opt_exp_avg, a.opt_exp_avg_sq = p(adam.exp_avg), p(adam.exp_avg_sq)
+        a.opt_n = policy.flat_params.numel()
+        a.opt_max_norm = float(max_grad_norm) if max_grad_norm else 0.0
+        a.opt_hyper_dev = p(adam.hyper_dev)
+        a.opt_step_dev = p(adam.step_dev, torch.int32)
     rc = _hip.lib().acktr_mlp_fused_step_f32(ctypes.byref(a), _hip.cur_stream(dev))
     _hip.check(rc, 'acktr_mlp_fused_step_f32')
 

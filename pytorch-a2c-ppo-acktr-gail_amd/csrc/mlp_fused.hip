@@ -5,14 +5,13 @@
 //
 // Why one workgroup: at 64 rows the whole step is ~4 MFLOP; run layer by layer it is ~30 dependent launches of
 // ~4.5 us each and nothing else.  Here the parameters (10 k floats), the gathered observations and all activations
-// live in the LDS of one CU (<= 150 KB) and the step is a chain of 64 x 64 x K products on the vector ALUs:
-//   512 threads = one group of 256 per tower; in a group thread (lo = t % 16, hi = t / 16) owns outputs
-//   (slow index hi + 16 i, fast index lo + 16 j), i, j < 4;
-//   lanes of a wave differ in the FAST index first, so every LDS read is either consecutive words (fast operand) or a
-//   broadcast of at most four addresses (slow operand); matrices whose rows are indexed by lanes have odd pitches.
+// live in the LDS of one CU (<= 150 KB) and the step is a chain of 64 x 64 x K products on the matrix cores:
+//   512 threads = one group of 256 per tower; the four waves of a group own the four 32 x 32 tiles of a product and feed
+//   v_mfma_f32_32x32x2_f32 (exact fp32) straight from LDS; matrices whose rows are indexed by lanes have odd pitches.
 // The backward overwrites activations in place (dh2 over h2, dh1 over h1), so no further LDS is needed.
 // Gradients are written straight into the caller's flat gradient buffer (overwrite, like the layer kernels).
 #include "loss_terms.hpp"
+#include "optim_terms.hpp"
 #include "../../include/acktr_hip.h"
 
 namespace acktr {
@@ -24,26 +23,22 @@ constexpr int MF_MAX_A = 8;
 constexpr int MF_PH = 65;         // pitch of [64 x 64] matrices in LDS (odd: rows indexed by lanes are conflict-free)
 constexpr int MF_THREADS = 512;   // two groups of 256: one per tower (critic / actor) wherever the towers are independent
 
-// acc[i][j] += sum_k a(hi + 16 i, k) * b(lo + 16 j, k)
+typedef float mf_f16 __attribute__((ext_vector_type(16)));
+
+// One 32 x 32 tile per wave on the matrix cores: acc(m, n) = sum_{k < K} a(m0 + m, k) * b(n0 + n, k), K even.
+// v_mfma_f32_32x32x2_f32 is an exact fp32 FMA chain; lane (li = l % 32, kh = l / 32) supplies a(m0 + li, k + kh) and
+// b(n0 + li, k + kh) straight from LDS.  Result layout: register v of lane l is (row 4 kh + (v & 3) + 8 (v >> 2), column li).
+// (The first version ran these products on the vector ALUs, 4 x 4 outputs per lane: 3.4 us per 64 x 64 x 64 stage,
+//  five stages; one dependent MFMA chain of 32 steps is 0.9 us.)
 template <class FA, class FB>
-__device__ __forceinline__ void mf_mm(float (&acc)[4][4], const int K, int lo, int hi, FA a, FB b) {
+__device__ __forceinline__ void mf_mm(mf_f16& acc, const int K, int m0, int n0, int li, int kh, FA a, FB b) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
 #pragma unroll 8
-    for (int k = 0; k < K; ++k) {
-        float av[4], bv[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) av[i] = a(hi + 16 * i, k);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bv[j] = b(lo + 16 * j, k);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_fmaf(av[i], bv[j], acc[i][j]);
-    }
+    for (int k = 0; k < K; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a(m0 + li, k + kh), b(n0 + li, k + kh), acc, 0, 0, 0);
 }
+// row / column of accumulator register v of this lane inside the tile
+__device__ __forceinline__ int mf_row(int v, int kh) { return 4 * kh + (v & 3) + 8 * (v >> 2); }
 
 struct MfLds {      // float offsets into the dynamic LDS block
     int w0c, w0a, w2c, w2a, wv, wm, b0c, b0a, b2c, b2a, bm, x, h1c, h1a, h2c, h2a, dv, dmean, red, total;
@@ -70,7 +65,9 @@ __host__ __device__ inline MfLds mf_layout(int IN, int A) {
 template <int ALGO>
 __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_step_args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int tid = threadIdx.x, tw = tid >> 8, t256 = tid & 255, lo = t256 & 15, hi = t256 >> 4;
+    const int tid = threadIdx.x, tw = tid >> 8, t256 = tid & 255;
+    // tower tw: four waves = the four 32 x 32 tiles of a 64 x 64 product
+    const int li = tid & 31, kh = (tid >> 5) & 1, m0 = 32 * ((tid >> 7) & 1), n0 = 32 * ((tid >> 6) & 1);
     const int IN = a.IN, A = a.A, B = a.B;
     const MfLds L = mf_layout(IN, A);
     const int PIN = L.pin;
@@ -104,18 +101,17 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_st
     }
     __syncthreads();
 
-    float acc[4][4];
+    mf_f16 acc;
     // ---- stage 1: h1 = tanh(x W0^T + b0), both towers        (model.py:208-216,226-227)
     {
         const float* W = sm + (tw ? L.w0a : L.w0c);
         const float* bias = sm + (tw ? L.b0a : L.b0c);
         float* H = sm + (tw ? L.h1a : L.h1c);
         const float* X = sm + L.x;
-        mf_mm(acc, IN, lo, hi, [&](int r, int k) { return X[r * PIN + k]; }, [&](int u, int k) { return W[u * PIN + k]; });
+        mf_mm(acc, (IN + 1) & ~1, m0, n0, li, kh, [&](int r, int k) { return k < IN ? X[r * PIN + k] : 0.f; },
+              [&](int u, int k) { return k < IN ? W[u * PIN + k] : 0.f; });
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) H[(hi + 16 * i) * MF_PH + lo + 16 * j] = tanhf(acc[i][j] + bias[lo + 16 * j]);
+        for (int v = 0; v < 16; ++v) H[(m0 + mf_row(v, kh)) * MF_PH + n0 + li] = tanhf(acc[v] + bias[n0 + li]);
     }
     __syncthreads();
     // ---- stage 2: h2 = tanh(h1 W2^T + b2)
@@ -124,11 +120,9 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_st
         const float* bias = sm + (tw ? L.b2a : L.b2c);
         const float* H1 = sm + (tw ? L.h1a : L.h1c);
         float* H2 = sm + (tw ? L.h2a : L.h2c);
-        mf_mm(acc, MF_H, lo, hi, [&](int r, int k) { return H1[r * MF_PH + k]; }, [&](int u, int k) { return W[u * MF_PH + k]; });
+        mf_mm(acc, MF_H, m0, n0, li, kh, [&](int r, int k) { return H1[r * MF_PH + k]; }, [&](int u, int k) { return W[u * MF_PH + k]; });
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) H2[(hi + 16 * i) * MF_PH + lo + 16 * j] = tanhf(acc[i][j] + bias[lo + 16 * j]);
+        for (int v = 0; v < 16; ++v) H2[(m0 + mf_row(v, kh)) * MF_PH + n0 + li] = tanhf(acc[v] + bias[n0 + li]);
     }
     __syncthreads();
     // ---- stage 3: heads, distribution, loss and its seeds -- one lane per row (wave 0)
@@ -234,11 +228,9 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_st
         const float* H1 = sm + (tw ? L.h1a : L.h1c);
         float* gw = tw ? a.gwa2 : a.gwc2;
         float* gb = tw ? a.gba2 : a.gbc2;
-        mf_mm(acc, MF_ROWS, lo, hi, [&](int u, int r) { return D2[r * MF_PH + u]; }, [&](int i, int r) { return H1[r * MF_PH + i]; });
+        mf_mm(acc, MF_ROWS, m0, n0, li, kh, [&](int u, int r) { return D2[r * MF_PH + u]; }, [&](int i, int r) { return H1[r * MF_PH + i]; });
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gw[(hi + 16 * i) * MF_H + lo + 16 * j] = acc[i][j];
+        for (int v = 0; v < 16; ++v) gw[(m0 + mf_row(v, kh)) * MF_H + n0 + li] = acc[v];
         if (t256 < MF_H) {
             float g = 0.f;
             for (int r = 0; r < MF_ROWS; ++r) g += D2[r * MF_PH + t256];
@@ -251,15 +243,13 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_st
         const float* D2 = sm + (tw ? L.h2a : L.h2c);
         const float* W = sm + (tw ? L.w2a : L.w2c);
         float* H1 = sm + (tw ? L.h1a : L.h1c);
-        mf_mm(acc, MF_H, lo, hi, [&](int r, int u) { return D2[r * MF_PH + u]; }, [&](int i, int u) { return W[u * MF_PH + i]; });
+        mf_mm(acc, MF_H, m0, n0, li, kh, [&](int r, int u) { return D2[r * MF_PH + u]; }, [&](int i, int u) { return W[u * MF_PH + i]; });
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float* p = H1 + (hi + 16 * i) * MF_PH + lo + 16 * j;
-                const float h = *p;
-                *p = acc[i][j] * (1.f - h * h);
-            }
+        for (int v = 0; v < 16; ++v) {
+            float* p = H1 + (m0 + mf_row(v, kh)) * MF_PH + n0 + li;
+            const float h = *p;
+            *p = acc[v] * (1.f - h * h);
+        }
     }
     __syncthreads();
     // ---- stage 7: dW0[u][k] = sum_r dh1[r][u] x[r][k]; db0[u] = sum_r dh1[r][u]
@@ -268,17 +258,79 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_st
         const float* X = sm + L.x;
         float* gw = tw ? a.gwa0 : a.gwc0;
         float* gb = tw ? a.gba0 : a.gbc0;
-        mf_mm(acc, MF_ROWS, lo, hi, [&](int u, int r) { return D1[r * MF_PH + u]; },
+        mf_mm(acc, MF_ROWS, m0, n0, li, kh, [&](int u, int r) { return D1[r * MF_PH + u]; },
               [&](int k, int r) { return k < IN ? X[r * PIN + k] : 0.f; });
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (lo + 16 * j < IN) gw[(hi + 16 * i) * IN + lo + 16 * j] = acc[i][j];
+        for (int v = 0; v < 16; ++v)
+            if (n0 + li < IN) gw[(m0 + mf_row(v, kh)) * IN + n0 + li] = acc[v];
         if (t256 < MF_H) {
             float g = 0.f;
             for (int r = 0; r < MF_ROWS; ++r) g += D1[r * MF_PH + t256];
             gb[t256] = g;
+        }
+    }
+    // ---- stage 8 (optional): clip_grad_norm_ + Adam over the flat buffers, same arithmetic as clip_update_kernel<0>
+    // (optim.hip).  The step is ONE workgroup, so the global norm needs no second launch: two ~5 us launches of a 57 us
+    // step.  The gradient stores above are this workgroup's own: visible to all its lanes behind the barrier.
+    if (a.opt_params) {
+        __syncthreads();
+        double* smd = reinterpret_cast<double*>(sm + L.red);     // 16 doubles of the 64-float reduction scratch (the kernel's
+        float* smo = sm + L.red + 40;                            // LDS is all dynamic: 160 KB leave no room for static arrays)
+        // every operand of the thread's (up to) six float4 groups is requested before the norm is reduced: one memory round
+        // trip for the whole tail instead of one per loop iteration (the scalar loops took 8 us)
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        constexpr int MAXG = 6;                                  // 6 * 512 * 4 = 12288 floats: MLPBase(64) with IN <= 64, A <= 8
+        const long n4 = a.opt_n / 4;                             // (flat buffers are padded to 16-byte slots: opt_n % 4 == 0)
+        v4 gv[MAXG], pv[MAXG], av[MAXG], bv[MAXG];
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u) {
+            const long i = tid + (long)u * MF_THREADS;
+            const long ic = i < n4 ? i : 0;
+            gv[u] = reinterpret_cast<const v4*>(a.opt_grads)[ic];
+            pv[u] = reinterpret_cast<const v4*>(a.opt_params)[ic];
+            av[u] = reinterpret_cast<const v4*>(a.opt_exp_avg)[ic];
+            bv[u] = reinterpret_cast<const v4*>(a.opt_exp_avg_sq)[ic];
+        }
+        double ss = 0.0;
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u)
+            if (tid + (long)u * MF_THREADS < n4)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const double x = (double)gv[u][j]; ss += x * x; }
+        ss = block_sum(ss, smd);
+        if (tid == 0) {
+            const int step = *a.opt_step_dev + 1;
+            *a.opt_step_dev = step;
+            const float lr = a.opt_hyper_dev[0], beta1 = a.opt_hyper_dev[1], beta2 = a.opt_hyper_dev[2];
+            float coef = 1.0f;
+            if (a.opt_max_norm > 0.f) {
+                const float c = a.opt_max_norm / ((float)sqrt(ss) + 1e-6f);
+                coef = c > 1.0f ? 1.0f : c;
+            }
+            smo[0] = coef;
+            smo[1] = (float)((double)lr / (1.0 - pow((double)beta1, (double)step)));
+            smo[2] = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+        }
+        __syncthreads();
+        const float coef = smo[0], step_size = smo[1], bc2_sqrt = smo[2];
+        const float beta1 = a.opt_hyper_dev[1], beta2 = a.opt_hyper_dev[2], eps = a.opt_hyper_dev[3];
+        const bool clip = a.opt_max_norm > 0.f;
+#pragma unroll
+        for (int u = 0; u < MAXG; ++u) {
+            const long i = tid + (long)u * MF_THREADS;
+            if (i < n4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float pi = pv[u][j], gi = gv[u][j], a1 = av[u][j], a2 = bv[u][j];
+                    if (clip) gi = gi * coef;
+                    adam_elem(pi, gi, a1, a2, beta1, beta2, eps, bc2_sqrt, step_size);
+                    pv[u][j] = pi; gv[u][j] = gi; av[u][j] = a1; bv[u][j] = a2;
+                }
+                reinterpret_cast<v4*>(a.opt_params)[i] = pv[u];
+                if (clip) reinterpret_cast<v4*>(a.opt_grads)[i] = gv[u];
+                reinterpret_cast<v4*>(a.opt_exp_avg)[i] = av[u];
+                reinterpret_cast<v4*>(a.opt_exp_avg_sq)[i] = bv[u];
+            }
         }
     }
 }
@@ -305,6 +357,11 @@ extern "C" int acktr_mlp_fused_step_f32(const acktr_mlp_step_args* args, void* s
     ACKTR_ARG(a.obs && a.actions, "mlp_fused_step: null observations / actions");
     ACKTR_ARG(a.algo != 0 || (a.old_logp && a.old_values && a.returns && a.adv), "mlp_fused_step: PPO needs rollout arrays");
     ACKTR_ARG(a.algo != 1 || a.returns, "mlp_fused_step: A2C needs returns");
+    ACKTR_ARG(!a.opt_params || (a.opt_grads && a.opt_exp_avg && a.opt_exp_avg_sq && a.opt_hyper_dev && a.opt_step_dev && a.opt_n > 0),
+              "mlp_fused_step: the optimiser tail needs all of its buffers");
+    ACKTR_ARG(!a.opt_params || (a.opt_n % 4 == 0 && a.opt_n <= 6L * MF_THREADS * 4 &&
+                                ((((uintptr_t)a.opt_params | (uintptr_t)a.opt_grads | (uintptr_t)a.opt_exp_avg | (uintptr_t)a.opt_exp_avg_sq) & 15) == 0)),
+              "mlp_fused_step: the optimiser tail needs 16-byte aligned flat buffers of n %% 4 == 0, n <= %d floats", 6 * MF_THREADS * 4);
     const MfLds L = mf_layout(a.IN, a.A);
     const int smem = L.total * (int)sizeof(float);
     ACKTR_ARG(smem <= 160 * 1024, "mlp_fused_step: LDS budget exceeded (%d bytes)", smem);

@@ -8,7 +8,7 @@
 //   torch/optim/adam.py:457,476,529-547          single-tensor Adam
 //   torch/optim/rmsprop.py:316-339               single-tensor RMSprop (not centred, no momentum)
 //   torch/optim/sgd.py:358-380                   SGD with momentum (first step: buf = grad)
-#include "common.hpp"
+#include "optim_terms.hpp"
 #include "../../include/acktr_hip.h"
 
 namespace acktr {
@@ -112,16 +112,8 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
     }
     auto upd = [&](float& pi, float& gi, float& a1, float& a2) {
         if (use_clip) gi = gi * coef;
-        if (MODE == 0) {
-            a1 = a1 + (1.0f - beta1) * (gi - a1);                    // exp_avg.lerp_(grad, 1-beta1)
-            a2 = a2 * beta2 + (1.0f - beta2) * gi * gi;              // mul_(beta2).addcmul_(g, g, 1-beta2)
-            const float denom = sqrtf(a2) / bc2_sqrt + eps;
-            pi = pi - lr_or_step * (a1 / denom);                     // addcdiv_(exp_avg, denom, -step_size)
-        } else {
-            a1 = a1 * beta2 + (1.0f - beta2) * gi * gi;              // square_avg.mul_(alpha).addcmul_(g, g, 1-alpha)
-            const float avg = sqrtf(a1) + eps;
-            pi = pi - lr_or_step * (gi / avg);                       // addcdiv_(grad, avg, -lr)
-        }
+        if (MODE == 0) adam_elem(pi, gi, a1, a2, beta1, beta2, eps, bc2_sqrt, lr_or_step);
+        else rmsprop_elem(pi, gi, a1, beta2, eps, lr_or_step);
     };
     for (long i = i_first; i < n4; i += (long)gridDim.x * OPT_THREADS) {
         v4 pv = pv0, gv = gv0, av = av0, bv = MODE == 0 ? bv0 : av0;

@@ -258,7 +258,14 @@ class KFACOptimizer(optim.Optimizer):
         for m in self._mods:
             out = view_a(m)
             if m.kind == 'AddBias':
-                out.fill_(float(B) / Bg)                          # ones^T (ones / B_global) over the local rows
+                # ones^T (ones / B_global) over the local rows: a constant.  Single process: nothing else writes the slot,
+                # so it is filled once per (slot, B, Bg); under data parallelism the in-place all-reduce sums into it every
+                # step, so it is refilled every step
+                done = self.__dict__.setdefault('_bias_a_done', set())
+                key_ = (m.oa, B, Bg, out.data_ptr())
+                if self.dp.active or key_ not in done:
+                    out.fill_(float(B) / Bg)
+                    done.add(key_)
             elif m.kind == 'Conv2d':
                 x, idx, sc, stride = conv_in[m.layer]
                 OC, C, KH, KW = m.param.shape

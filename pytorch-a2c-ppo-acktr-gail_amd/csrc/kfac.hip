@@ -160,6 +160,9 @@ static int cov_g_conv_t(const float* dy, int B, int OC, float alpha, float* out,
     else rc = launch_gemm<64, 128, 2, 2>(gop, gop, e, OC, OC, R, ns, s);
     if (rc) return rc;
     if (ns > 1) rc = launch_slab_reduce(out, ws, ns, (long)OC * OC, (long)OC * OC, alpha, 0, s);
+    // OC <= the tile height of either form: no tile lies below the diagonal, so none was skipped, and (i, j) / (j, i)
+    // are the same products summed in the same order -- the factor is exactly symmetric without a mirroring pass
+    if (OC <= (OC <= 32 ? 32 : 64)) return rc;
     return rc ? rc : launch_symmetrize_lower(out, OC, s);
 }
 
@@ -418,6 +421,7 @@ extern "C" int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, 
         e.scale = alpha;
         e.symmetric = 1;
         int rc1 = gemm_rowmajor(a, 1, lda, a, 1, lda, e, D, D, B, 1, s);
+        if (D <= 32) return rc1;           // one 128x32 / 32x128 tile row: nothing skipped, exactly symmetric as computed
         return rc1 ? rc1 : launch_symmetrize_lower(out, D, s);
     }
     RowMajorEpi e = row_major_epi(ws, D, D, D);
@@ -426,6 +430,7 @@ extern "C" int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, 
     int rc = gemm_rowmajor(a, 1, lda, a, 1, lda, e, D, D, B, ns, s);
     if (rc) return rc;
     rc = launch_slab_reduce(out, ws, ns, (long)D * D, (long)D * D, alpha, 0, s);
+    if (D <= 32) return rc;
     return rc ? rc : launch_symmetrize_lower(out, D, s);
 }
 

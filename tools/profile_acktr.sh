@@ -11,6 +11,9 @@ export TMPDIR=/tmp
 PROG="python3 tools/acktr_bench.py"
 timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- $PROG > $OUT/kt.log 2>&1
 cp $(find $OUT/kt -name '*kernel_stats.csv' | head -1) $OUT/kernel_stats.csv
+# (the counter passes keep every eigensolve on the hand-written Jacobi: rocprofv3's counter collection crashed inside a
+#  dispatch issued from the host thread that runs rocSOLVER beside it)
+export ACKTR_EIG_BLOCK_MAX_N=2048
 for C in FETCH_SIZE WRITE_SIZE; do
     timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d $OUT/$C -o pmc -- $PROG > $OUT/$C.log 2>&1
     python3 tools/pmc_summary.py $(find $OUT/$C -name '*counter_collection.csv' | head -1) $OUT/pmc_$C.csv

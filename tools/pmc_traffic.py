@@ -8,8 +8,8 @@ bytes, so it is doubled; WRITE_SIZE is taken as is.  bench.py reads the JSON for
 import csv, json, sys
 OPS = [('conv8s4_fwd', 'SwGeom<8, 8, 4, 84, 84, 4,'), ('conv4s2_fwd', 'SwGeom<4, 4, 2, 20, 20, 32,'),
        ('conv3s1_fwd', 'SwGeom<3, 3, 1, 9, 9, 64,'), ('conv3s1_dgrad', 'SwGeom<3, 3, 1, 11, 11, 32,'),
-       ('conv4s2_dgrad', 'SwGeom<2, 2, 1, 11, 11, 64,'), ('conv8s4_wgrad', 'ConvOutKC<400>'),
-       ('conv4s2_wgrad', 'ConvOutKC<81>'), ('conv3s1_wgrad', 'conv3_wgrad_sa_kernel'),
+       ('conv4s2_dgrad', 'SwGeom<2, 2, 1, 11, 11, 64,'), ('conv8s4_wgrad', 'conv1_wgrad_sa_kernel'),
+       ('conv4s2_wgrad', 'conv2_wgrad_sa_kernel'), ('conv3s1_wgrad', 'conv3_wgrad_sa_kernel'),
        ('linear1568x512_fwd', 'DenseKCT<true>, acktr::DenseKCT<true>'),
        ('linear1568x512_wgrad', 'DenseRCT<true>, acktr::DenseRCT<true>'),
        ('linear1568x512_dgrad', 'DenseKCT<true>, acktr::DenseRCT<true>')]

@@ -47,8 +47,12 @@ def profile_summary():
     torch.cuda.synchronize()
     for name, recs in profiler.items():
         ms = [s.elapsed_time(e) for s, e, _ in recs]
-        out[name] = dict(calls=len(ms), avg_ms=sum(ms) / len(ms), total_ms=sum(ms),
-                         flops_per_call=sum(w for _, _, w in recs) / len(recs))
+        # an event bracket also counts GPU idle time when the host is late with the launch inside it (one 35 ms host
+        # stall once turned a 78 us kernel into a 2.2 ms "average"): brackets above 3x the median are left out
+        med = sorted(ms)[len(ms) // 2]
+        kept = [m for m in ms if m <= 3.0 * med] or ms
+        out[name] = dict(calls=len(ms), avg_ms=sum(kept) / len(kept), total_ms=sum(kept) / len(kept) * len(ms),
+                         flops_per_call=sum(w for _, _, w in recs) / len(recs), outliers_dropped=len(ms) - len(kept))
     return out
 
 

@@ -128,11 +128,11 @@ static int conv3_wgrad_sa(const float* x, const float* dy, float* dw, float* db,
 // 8x8 stride-4 layer on 84x84x4 frames with OC == 32: stationary accumulators, one workgroup per CU (conv_wgrad_sa.hpp)
 static bool sa1_wgrad_ok(int geom, int C, int OC, int B) {
     static const bool off = getenv("ACKTR_CONV1_WGRAD_TILE") != nullptr;     // tuning / comparison switch
-    return !off && geom == GEOM_8S4 && C == S1_C && OC == S1_OC && B >= 64;
+    return !off && geom == GEOM_8S4 && C == S1_C && OC == S1_OC && B >= 256;     // (B = 80: the tile GEMM's ~400 slices win)
 }
 static int sa1_wgrad_slabs(int B) {
     const int cus = sw_num_cus();
-    const int by_work = B * S1_GROUPS / 40;            // at least ten row-pair groups per wave
+    const int by_work = B * S1_GROUPS / 20;            // at least five row-pair groups per wave
     return by_work < cus ? (by_work < 1 ? 1 : by_work) : cus;
 }
 static int conv1_wgrad_sa(const float* x, const int64_t* idx, const float* dy, float* dw, float* db, int B, float scale,
@@ -158,7 +158,7 @@ static int conv1_wgrad_sa(const float* x, const int64_t* idx, const float* dy, f
 // 4x4 stride-2 layer on 20x20x32 activations with OC == 64: stationary accumulators (conv_wgrad_sa.hpp)
 static bool sa2_wgrad_ok(int geom, int C, int OC, int B, const int64_t* idx) {
     static const bool off = getenv("ACKTR_CONV2_WGRAD_TILE") != nullptr;     // tuning / comparison switch
-    return !off && geom == GEOM_4S2 && C == S2_C && OC == S2_OC && B >= 64 && !idx && (long)B * S2_IMG < (1L << 31);
+    return !off && geom == GEOM_4S2 && C == S2_C && OC == S2_OC && B >= 256 && !idx && (long)B * S2_IMG < (1L << 31);
 }
 static int sa2_wgrad_slabs(int B) {
     const int cus = sw_num_cus();

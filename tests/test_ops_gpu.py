@@ -160,9 +160,9 @@ def test_conv3_wgrad_stationary_accumulator(B):
     assert torch.equal(dw2, dw)
 
 
-@pytest.mark.parametrize('B,gather', [(64, False), (70, True), (300, True), (1024, False)])
+@pytest.mark.parametrize('B,gather', [(256, False), (270, True), (300, True), (1024, False)])
 def test_conv1_wgrad_stationary_accumulator(B, gather):
-    """conv_wgrad_sa.hpp, 8x8 stride-4 layer on 84x84x4 frames (B >= 64): ragged reduction ranges, gathered minibatch rows
+    """conv_wgrad_sa.hpp, 8x8 stride-4 layer on 84x84x4 frames (B >= 256): ragged reduction ranges, gathered minibatch rows
     out of a larger store, the /255 input scale, bias sums; against torch fp32 on the CPU, and run-to-run deterministic."""
     from a2c_ppo_acktr import ops
     g = torch.Generator().manual_seed(B)
@@ -184,9 +184,9 @@ def test_conv1_wgrad_stationary_accumulator(B, gather):
     assert torch.equal(dw2, dw)
 
 
-@pytest.mark.parametrize('B', [64, 71, 300, 1024])
+@pytest.mark.parametrize('B', [256, 271, 300, 1024])
 def test_conv2_wgrad_stationary_accumulator(B):
-    """conv_wgrad_sa.hpp, 4x4 stride-2 layer on 20x20x32 activations (B >= 64): ragged image ranges, the single-position
+    """conv_wgrad_sa.hpp, 4x4 stride-2 layer on 20x20x32 activations (B >= 256): ragged image ranges, the single-position
     eleventh block of every image, bias sums, the last image's tail; against torch fp32 on the CPU."""
     from a2c_ppo_acktr import ops
     g = torch.Generator().manual_seed(B + 1)

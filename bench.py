@@ -427,7 +427,7 @@ def main():
             import glob
             import re
             cands = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic_*.json'))
-            key = lambda f: tuple(int(x) for x in re.findall(r'\d+', os.path.basename(f)))     # (round, version)
+            key = lambda f: (tuple(int(x) for x in re.findall(r'\d+', os.path.basename(f))), os.path.basename(f))   # round, tag
             tp = max(cands, key=key)
             traffic = json.load(open(tp))[dom[0]]['traffic_bytes']
             traffic_src = 'profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)' % os.path.basename(tp)

@@ -191,7 +191,7 @@ class PPO():
                 # overlapped buckets run launch by launch: replaying the three graph pieces around the two
                 # collectives measured 13.2 ms per update against 11.9 eager (and 11.8 for two graphs around ONE
                 # un-overlapped all-reduce, which then pays the whole transfer on the critical path)
-                graph_ok = False
+                graph_ok = graph_ok and os.environ.get('ACKTR_DP_GRAPH', '0') == '1'
             # Single process: ONE graph per epoch; step k reads its rows from slice k of a device buffer that receives the
             # whole epoch's permutation in one copy -- a 512-byte host-to-device copy between
             # every two replays cost 4.4 us of device time plus an exposed graph-launch latency per step (10 % of the
@@ -206,14 +206,18 @@ class PPO():
                             self._step(dict(b, idx=self._idx_all[k]), capturing=True)
                             self.optimizer.step_count -= 1
                     self._graphs = (g,)
-                else:                                       # the all-reduce sits between the two graphs
-                    g1, g3 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                else:                                       # the all-reduce(s) sit between the graphs
+                    g1, g2, g3 = torch.cuda.CUDAGraph(), None, torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g1):
-                        self._fwd_bwd(b)
+                        self._fwd_bwd(b, phase=1 if split is not None else None)
+                    if split is not None:
+                        g2 = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g2):
+                            self._fwd_bwd(b, phase=2)
                     with torch.cuda.graph(g3):
                         self.optimizer.step(self.max_grad_norm, capturing=True)
                         self.optimizer.step_count -= 1
-                    self._graphs = (g1, None, g3)
+                    self._graphs = (g1, g2, g3)
                 self._graph_key = key
             self._seen_key = key
             for e in range(self.ppo_epoch):

@@ -312,14 +312,29 @@ int acktr_kfac_kl_clip_f32(const float* v, const float* g, long n, float lr, flo
 int acktr_gail_mix_concat_f32(const float* policy_state, const float* policy_action, const float* expert_state,
                               const float* expert_action, const float* alpha, int B, int Ds, int Da, float* x_out,
                               void* stream);
+/* the same with the policy rows read through a minibatch index (storage.py:127-140 fused in): policy row b =
+ * state_rows[idx[b], :] | action_rows[idx[b], :] (idx NULL: row b); the caller guarantees 0 <= idx[b] < rows of the two
+ * arrays.  mix_copies 1 or 2: with 2, x_out has 4B rows and rows [3B, 4B) repeat the mixup rows (the stacked weight
+ * gradients below pair them with the penalty's d a while rows [2B, 3B) are reused for the double backward's operands). */
+int acktr_gail_mix_concat_idx_f32(const float* state_rows, const float* action_rows, const int64_t* idx,
+                                  const float* expert_state, const float* expert_action, const float* alpha, int B, int Ds,
+                                  int Da, int mix_copies, float* x_out, void* stream);
 /* gail.py:78-85 on the trunk outputs d[3B] of those rows: loss_out[0] = BCE(expert, 1) + BCE(policy, 0) (means);
  * seed[3B] = d loss / d d for the policy / expert rows and 1 for the mixup rows (the `ones` of gail.py:45);
- * seed_bce[3B] = the same with 0 on the mixup rows. */
-int acktr_gail_bce_seed_f32(const float* d, int B, float* seed, float* seed_bce, float* loss_out, void* stream);
+ * seed_bce[3B] = the same with 0 on the mixup rows.  stacked != 0: seed_bce has 4B rows, 1 on [2B, 3B), 0 on [3B, 4B). */
+int acktr_gail_bce_seed_f32(const float* d, int B, int stacked, float* seed, float* seed_bce, float* loss_out, void* stream);
 /* gail.py:54: loss_out[1] = lambda * mean((||g_b|| - 1)^2) for g[B, D] = d D / d x at the mixup rows, and
- * r[B, D] = d loss_out[1] / d g (the seed of the double backward).  row_scratch: B floats. */
+ * r[B, D] = d loss_out[1] / d g (the seed of the double backward).  row_scratch: B floats, needed (and used) only
+ * above B = 4096. */
 int acktr_gail_pen_seed_f32(const float* g, int B, int D, float lambda_, float* r, float* row_scratch, float* loss_out,
                             void* stream);
+/* gail.py:93 (loss.backward()) for the three Linear layers at once, two launches: dw_l[out_l, in_l] = A_l^T X_l summed over
+ * all `rows` rows of the row-stacked operands (a1, a2: [rows, H]; a3: [rows]; x: [rows, D]; h1, h2: [rows, H]) and
+ * db_l = the column sums of A_l over the rows outside [skip_lo, skip_hi).  The host stacks, per layer, the ordinary
+ * backward's rows, the double backward's outer-product pair (skipped by the bias sums) and the penalty's rows. */
+int acktr_gail_param_grads_f32(const float* a1, const float* x, const float* a2, const float* h1, const float* a3,
+                               const float* h2, int rows, int D, int H, int skip_lo, int skip_hi, float* dw1, float* db1,
+                               float* dw2, float* db2, float* dw3, float* db3, void* stream);
 /* element-wise links of the (double) backward through tanh layers, h = tanh(.) stored, n elements, `cols` columns:
  * mode 0: out0 = (1-h^2) in0;  1: out0 = (1-h^2) in0, out1 = in1*in0;  2: out0 = (1-h^2) in0,
  * out1 = (1-h^2)(-2 h w[col] in0);  3: out0 = (1-h^2)(in0 - 2 h in1). */

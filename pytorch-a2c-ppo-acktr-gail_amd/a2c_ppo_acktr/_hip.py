@@ -126,7 +126,9 @@ _PROTOS = {
     'acktr_kfac_precondition_batched_f32': (c_i, [ctypes.POINTER(PrecondJob), c_i, c_f, c_p]),
     'acktr_kfac_kl_clip_f32': (c_i, [c_p, c_p, c_l, c_f, c_f, c_p, c_p, c_p]),
     'acktr_gail_mix_concat_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p, c_p]),
-    'acktr_gail_bce_seed_f32': (c_i, [c_p, c_i, c_p, c_p, c_p, c_p]),
+    'acktr_gail_mix_concat_idx_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p, c_p]),
+    'acktr_gail_bce_seed_f32': (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    'acktr_gail_param_grads_f32': (c_i, [c_p] * 6 + [c_i] * 5 + [c_p] * 7),
     'acktr_gail_pen_seed_f32': (c_i, [c_p, c_i, c_i, c_f, c_p, c_p, c_p, c_p]),
     'acktr_gail_tanh_link_f32': (c_i, [c_i, c_p, c_p, c_p, c_p, c_l, c_i, c_p, c_p, c_p]),
     'acktr_gail_reward_f32': (c_i, [c_p, c_l, c_p, c_p]),

@@ -106,95 +106,108 @@ class Discriminator(nn.Module):
         return h1, h2, d
 
     # ------------------------------------------------------------------ one minibatch: losses + all gradients
-    def _losses_and_grads(self, policy_state, policy_action, expert_state, expert_action, alpha, lambda_=10.0):
+    def _losses_and_grads(self, policy_state, policy_action, expert_state, expert_action, alpha, lambda_=10.0,
+                          policy_idx=None):
         """gail.py:67-93 for one minibatch: returns a device tensor [gail_loss, grad_pen] and leaves
-        d(gail_loss + grad_pen)/d(parameters) in self.flat_grads."""
+        d(gail_loss + grad_pen)/d(parameters) in self.flat_grads.  With `policy_idx` (int64 device tensor [B]) the policy
+        rows are rows policy_idx of the two [rows, D] arrays: the minibatch gather runs inside the first kernel."""
         L = _hip.lib()
         dev = self.flat_params.device
         st = _hip.cur_stream(dev)
         W1, b1, W2, b2, w3, b3 = list(self.trunk.parameters())
-        B, Ds, Da = policy_state.shape[0], policy_state.shape[1], policy_action.shape[1]
+        Ds, Da = policy_state.shape[1], policy_action.shape[1]
+        B = policy_state.shape[0] if policy_idx is None else policy_idx.numel()
         D, H = Ds + Da, W1.shape[0]
         c = lambda t_: t_.to(device=dev, dtype=f32).contiguous()
         ps, pa, es, ea, al = c(policy_state), c(policy_action), c(expert_state), c(expert_action), c(alpha).view(-1)
         assert es.shape == (B, Ds) and ea.shape == (B, Da) and al.numel() == B, 'expert / policy batch shapes differ'
         e = lambda *s: torch.empty(*s, dtype=f32, device=dev)
-        X = e(3 * B, D)
-        _hip.check(L.acktr_gail_mix_concat_f32(_hip.dev_ptr(ps), _hip.dev_ptr(pa), _hip.dev_ptr(es), _hip.dev_ptr(ea),
-                                               _hip.dev_ptr(al), B, Ds, Da, _hip.dev_ptr(X), st), 'acktr_gail_mix_concat_f32')
-        h1, h2, d = self._forward(X)                                   # all 3B rows at once
-        seed, seed_bce, loss = e(3 * B, 1), e(3 * B, 1), torch.zeros(2, dtype=f32, device=dev)
-        _hip.check(L.acktr_gail_bce_seed_f32(_hip.dev_ptr(d), B, _hip.dev_ptr(seed), _hip.dev_ptr(seed_bce),
+        # Row layout of every [4B, .] array: [0, B) policy, [B, 2B) expert, [2B, 3B) mixup, [3B, 4B) mixup again.  The
+        # trunk runs over all 4B rows (these launches are latency-bound, the repeated rows are free); afterwards rows
+        # [2B, 3B) of X / h1 / h2 are overwritten by the double backward's r / d v1 / t2'*d u2 and rows [3B, 4B) keep the
+        # mixup activations, so that each layer's weight gradient -- ordinary backward + the double backward's outer
+        # product + the penalty's backward (gail.py:93 on gail_loss + grad_pen) -- is ONE product over the 4B stacked rows.
+        m, t_ = slice(2 * B, 3 * B), slice(3 * B, 4 * B)
+        X = e(4 * B, D)
+        _hip.check(L.acktr_gail_mix_concat_idx_f32(_hip.dev_ptr(ps), _hip.dev_ptr(pa), _hip.dev_ptr(policy_idx, torch.int64),
+                                                   _hip.dev_ptr(es), _hip.dev_ptr(ea), _hip.dev_ptr(al), B, Ds, Da, 2,
+                                                   _hip.dev_ptr(X), st), 'acktr_gail_mix_concat_idx_f32')
+        h1, h2, d = self._forward(X)
+        seed, seed_bce, loss = e(3 * B, 1), e(4 * B, 1), e(2)
+        _hip.check(L.acktr_gail_bce_seed_f32(_hip.dev_ptr(d), B, 1, _hip.dev_ptr(seed), _hip.dev_ptr(seed_bce),
                                              _hip.dev_ptr(loss), st), 'acktr_gail_bce_seed_f32')
-        # first backward, all rows: policy / expert rows carry the BCE seeds, the mixup rows carry `ones` (gail.py:45-52)
-        a2 = ops.linear_dgrad(seed, w3, gate_src=h2, gate='tanh')       # rows<2B: d a2 (BCE); mixup rows: u2 = t2' * w3
-        v = ops.linear_dgrad(a2, W2)                                    # rows<2B: d h1 (BCE); mixup rows: v1
-        a1 = e(3 * B, H)
+        # first backward, rows [0, 3B): policy / expert rows carry the BCE seeds, the mixup rows carry `ones` (gail.py:45-52)
+        a2, a1 = e(4 * B, H), e(4 * B, H)
+        ops.linear_dgrad(seed, w3, gate_src=h2[:3 * B], gate='tanh', out=a2[:3 * B])   # rows<2B: d a2 (BCE); mixup: u2 = t2' * w3
+        v = ops.linear_dgrad(a2[:3 * B], W2)                            # rows<2B: d h1 (BCE); mixup rows: v1
         link = lambda mode, h, i0, i1, w, o0, o1: _hip.check(L.acktr_gail_tanh_link_f32(
             mode, _hip.dev_ptr(h), _hip.dev_ptr(i0), _hip.dev_ptr(i1), _hip.dev_ptr(w), i0.numel(), H, _hip.dev_ptr(o0),
             _hip.dev_ptr(o1), st), 'acktr_gail_tanh_link_f32')
-        link(0, h1, v, None, None, a1, None)                            # rows<2B: d a1 (BCE); mixup rows: u1 = t1' * v1
-        m = slice(2 * B, 3 * B)
-        u2, v1, u1, h1m, h2m = a2[m], v[m], a1[m], h1[m], h2[m]
+        link(0, h1[:3 * B], v, None, None, a1[:3 * B], None)            # rows<2B: d a1 (BCE); mixup rows: u1 = t1' * v1
+        v1, u1, h1m, h2m = v[m], a1[m], h1[t_], h2[t_]
         g = ops.linear_dgrad(u1, W1)                                    # d D / d x at the mixup points  [B, D]
-        r, rows = e(B, D), e(B)
-        _hip.check(L.acktr_gail_pen_seed_f32(_hip.dev_ptr(g), B, D, float(lambda_), _hip.dev_ptr(r), _hip.dev_ptr(rows),
-                                             _hip.dev_ptr(loss), st), 'acktr_gail_pen_seed_f32')
+        r = X[m]                                                        # the mixup inputs live on in X[3B:4B]
+        _hip.check(L.acktr_gail_pen_seed_f32(_hip.dev_ptr(g), B, D, float(lambda_), _hip.dev_ptr(r),
+                                             _hip.dev_ptr(e(B)) if B > 4096 else None, _hip.dev_ptr(loss), st),
+                   'acktr_gail_pen_seed_f32')
         # double backward (autograd of gail.py:46-54 through create_graph=True), mixup rows only
         du1 = ops.linear_fwd(r, W1, None, None)                         # d u1 = r W1^T
-        dv1, dt1 = e(B, H), e(B, H)
+        dv1, dt1 = h1[m], e(B, H)
         link(1, h1m, du1, v1, None, dv1, dt1)
         du2 = ops.linear_fwd(dv1, W2, None, None)                       # d u2 = d v1 W2^T
-        prod, da2p = e(B, H), e(B, H)
+        prod, da2p = h2[m], a2[t_]
         link(2, h2m, du2, None, w3.view(-1), prod, da2p)                # t2' * d u2 (-> d w3) and d a2 of the penalty
         dh1p = ops.linear_dgrad(da2p, W2)
-        da1p = e(B, H)
-        link(3, h1m, dh1p, dt1, None, da1p, None)
-        # parameter gradients.  Weight gradients of the ordinary backward over all 3B rows (mixup rows replaced by the
-        # penalty's d a), then the two outer-product terms of the double backward added on top.
+        link(3, h1m, dh1p, dt1, None, a1[t_], None)                     # d a1 of the penalty
+        # parameter gradients: per layer  [BCE rows; u; d a (penalty)]^T [inputs; double-backward operand; mixup inputs];
+        # the u rows [2B, 3B) take no part in the bias sums
         gW1, gb1, gW2, gb2, gw3, gb3 = [self._gview(i) for i in range(6)]
-        u2c, u1c = u2.clone(), u1.clone()                               # the rows are overwritten just below
-        a2[m].copy_(da2p)
-        a1[m].copy_(da1p)
-        ops.linear_wgrad(a1, X, gW1, gb1.view(-1))
-        ops.linear_wgrad(a2, h1, gW2, gb2.view(-1))
-        ops.linear_wgrad(seed_bce, h2, gw3, gb3.view(-1))
-        ops.gemm(u1c, r, out=gW1, trans_a=True, accumulate=True)        # d W1 += u1^T r
-        ops.gemm(u2c, dv1, out=gW2, trans_a=True, accumulate=True)      # d W2 += u2^T d v1
-        ones = torch.ones(B, 1, dtype=f32, device=dev)
-        ops.gemm(ones, prod, out=gw3, trans_a=True, accumulate=True)    # d w3 += sum_b t2' * d u2
+        _hip.check(L.acktr_gail_param_grads_f32(
+            _hip.dev_ptr(a1), _hip.dev_ptr(X), _hip.dev_ptr(a2), _hip.dev_ptr(h1), _hip.dev_ptr(seed_bce), _hip.dev_ptr(h2),
+            4 * B, D, H, 2 * B, 3 * B, _hip.dev_ptr(gW1), _hip.dev_ptr(gb1), _hip.dev_ptr(gW2), _hip.dev_ptr(gb2),
+            _hip.dev_ptr(gw3), _hip.dev_ptr(gb3), st), 'acktr_gail_param_grads_f32')
         return loss
 
     # ------------------------------------------------------------------ one optimiser step, replayed from a hipGraph
-    def _step(self, policy_state, policy_action, expert_state, expert_action, alpha):
+    def _step(self, policy_state, policy_action, expert_state, expert_action, alpha, policy_idx=None):
         """losses + gradients + Adam for one minibatch (gail.py:67-93).  The ~45 launches of a step are latency-bound,
         so from the third step of a given batch shape on they are replayed from a captured hipGraph whose inputs are
-        persistent buffers refilled before every replay (ACKTR_HIP_GRAPH=0 disables it)."""
+        persistent buffers refilled before every replay (ACKTR_HIP_GRAPH=0 disables it).  With `policy_idx` the policy
+        operands are the whole [rows, D] rollout arrays (read in place) and only the index batch is refilled."""
         dev = self.flat_params.device
+        call = lambda ps, pa, es, ea, al, ix: self._losses_and_grads(ps, pa, es, ea, al, policy_idx=ix)
         if os.environ.get('ACKTR_HIP_GRAPH', '1') == '0' or ops.profiler is not None:
-            loss = self._losses_and_grads(policy_state, policy_action, expert_state, expert_action, alpha)
+            loss = call(policy_state, policy_action, expert_state, expert_action, alpha, policy_idx)
             self.optimizer.step(max_grad_norm=None)                     # flat Adam; grads were just overwritten
             return loss
-        B, Ds, Da = policy_state.shape[0], policy_state.shape[1], policy_action.shape[1]
-        key = (B, Ds, Da, self.flat_params.data_ptr())
+        Ds, Da = policy_state.shape[1], policy_action.shape[1]
+        B = policy_state.shape[0] if policy_idx is None else policy_idx.numel()
+        key = (B, Ds, Da, self.flat_params.data_ptr(),
+               None if policy_idx is None else (policy_state.data_ptr(), policy_action.data_ptr(), policy_state.shape[0]))
         st = self.__dict__.get('_gstate')
         if st is None or st['key'] != key:
             e = lambda *s: torch.empty(*s, dtype=f32, device=dev)
-            st = dict(key=key, seen=0, graph=None, loss=None,
-                      inp=(e(B, Ds), e(B, Da), e(B, Ds), e(B, Da), e(B, 1)))
+            if policy_idx is None:
+                inp = [e(B, Ds), e(B, Da), e(B, Ds), e(B, Da), e(B, 1), None]
+            else:                                                       # the rollout arrays themselves + an index buffer
+                inp = [policy_state, policy_action, e(B, Ds), e(B, Da), e(B, 1), torch.zeros(B, dtype=torch.int64, device=dev)]
+            st = dict(key=key, seen=0, graph=None, loss=None, inp=inp)
             self.__dict__['_gstate'] = st
-        for dst, src in zip(st['inp'], (policy_state, policy_action, expert_state, expert_action, alpha)):
+        srcs = (policy_state, policy_action, expert_state, expert_action, alpha, policy_idx)
+        for i, (dst, src) in enumerate(zip(st['inp'], srcs)):
+            if dst is None or (policy_idx is not None and i < 2):
+                continue
             dst.copy_(src.reshape(dst.shape), non_blocking=True)
         if st['graph'] is None:
             if st['seen'] < 2:                                          # warm workspaces / optimiser state launch by launch
                 st['seen'] += 1
-                loss = self._losses_and_grads(*st['inp'])
+                loss = call(*st['inp'])
                 self.optimizer.step(max_grad_norm=None)
                 return loss
             self.optimizer.prepare()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                st['loss'] = self._losses_and_grads(*st['inp'])
+                st['loss'] = call(*st['inp'])
                 self.optimizer.step(max_grad_norm=None, capturing=True)
                 self.optimizer.step_count -= 1
             st['graph'] = g
@@ -215,16 +228,34 @@ class Discriminator(nn.Module):
         """gail.py:57-95"""
         self._check_dev()
         self.train()
-        policy_data_generator = rollouts.feed_forward_generator(None, mini_batch_size=expert_loader.batch_size)
+        # gail.py:60 draws its policy batches from rollouts.feed_forward_generator(None, mini_batch_size=...).  Of the
+        # eight gathered tensors of a batch only the states and actions are used, so for this package's RolloutStorage
+        # the same index batches (same ONE randperm) are taken directly and the gather is fused into the first kernel.
+        light = (hasattr(rollouts, 'minibatch_index_batches') and rollouts.obs.dim() == 3 and rollouts.obs.is_cuda
+                 and rollouts.obs.dtype == f32 and rollouts.actions.dtype == f32)
         losses = []
-        for expert_batch, policy_batch in zip(_expert_batches(expert_loader), policy_data_generator):
-            policy_state, policy_action = policy_batch[0], policy_batch[2]
+        if light:
+            T = rollouts.rewards.size(0)
+            obs_rows = rollouts.obs[:T].reshape(-1, rollouts.obs.size(-1))
+            act_rows = rollouts.actions.reshape(-1, rollouts.actions.size(-1))
+
+            def batches():                                              # a generator, so that the permutation is drawn at the
+                for ix in rollouts.minibatch_index_batches(mini_batch_size=expert_loader.batch_size):
+                    yield ix                                            # first next(), after the expert loader's own draws
+            batches = batches()
+        else:
+            batches = rollouts.feed_forward_generator(None, mini_batch_size=expert_loader.batch_size)
+        for expert_batch, policy_batch in zip(_expert_batches(expert_loader), batches):
             expert_state, expert_action = expert_batch
             expert_state = obsfilt(expert_state.numpy(), update=False)
             expert_state = torch.FloatTensor(expert_state).to(self.device)
             expert_action = expert_action.to(self.device)
             alpha = torch.rand(expert_state.size(0), 1)                 # gail.py:35 (CPU RNG stream, F7)
-            losses.append(self._step(policy_state, policy_action, expert_state, expert_action, alpha))
+            if light:
+                losses.append(self._step(obs_rows, act_rows, expert_state, expert_action, alpha,
+                                         policy_idx=policy_batch.contiguous()))
+            else:
+                losses.append(self._step(policy_batch[0], policy_batch[2], expert_state, expert_action, alpha))
         tot = torch.stack(losses).sum(dim=1).cpu()                      # ONE host sync per update (the reference: one per batch)
         return float(tot.double().sum().item()) / len(losses)
 

@@ -414,6 +414,104 @@ static int skinny_slices(int B) {
     return n;
 }
 
+// ==========================================================================================
+// Small layers (K <= 128, N <= 128, few thousand rows at most: the GAIL discriminator's 23 -> 100 -> 100 trunk, MLP
+// policies at rollout batch sizes).  These launches are pure latency: the tile GEMM's LDS staging and its barrier per K tile
+// cost ~9.5 us for 10 MFLOP.  Here ONE wave owns a 32x32 output tile and its operands go from global memory straight into
+// the MFMA operand registers, all loads in flight at once, no LDS, no barrier:
+//   A (activations, k contiguous): lane (li, kh) loads 16-byte quads 2j + kh of row m0 + li; element e of quad j feeds
+//     MFMA step 4j + e, i.e. that step's k is 8j + 4kh + e -- the sum over k does not care about the order as long as B agrees;
+//   B k-contiguous (forward, w[n, k]): the same quads of row n0 + li;  B n-contiguous (dgrad, w[k, n]): dword
+//     w[(8j + 4kh + e) * N + n0 + li], coalesced across li.
+// Rows that are not 16-byte aligned or K % 4 != 0 (the 23-wide first layer) take dword loads with k = 2s + kh.
+// ==========================================================================================
+constexpr int SMALL_MAX_K = 128, SMALL_MAX_N = 128, SMALL_MAX_M = 8192;
+template <bool VEC, bool BKC>
+__global__ __launch_bounds__(64) void small_linear_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          const float* __restrict__ bias, const float* __restrict__ gate_src,
+                                                          float* __restrict__ c, int M, int N, int K, int act, int gate,
+                                                          int accumulate) {
+    const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int lane = threadIdx.x, li = lane & 31, kh = lane >> 5;
+    const int row = m0 + li, col = n0 + li;
+    const bool rok = row < M, cok = col < N;
+    f32x16 acc;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) acc[v] = 0.f;
+    if constexpr (VEC) {
+        const int nq = K / 4;
+        const float* ap = a + (long)(rok ? row : 0) * K;
+        f32x4 av[SMALL_MAX_K / 8], bv[SMALL_MAX_K / 8];
+#pragma unroll
+        for (int j = 0; j < SMALL_MAX_K / 8; ++j) {                  // (no early exit: the arrays must keep static indices)
+            const int q = 2 * j + kh;
+            const bool ok = q < nq;
+            av[j] = (ok && rok) ? *reinterpret_cast<const f32x4*>(ap + 4 * q) : zero4();
+            if constexpr (BKC) {
+                bv[j] = (ok && cok) ? *reinterpret_cast<const f32x4*>(b + (long)col * K + 4 * q) : zero4();
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bv[j][e] = (ok && cok) ? b[(long)(4 * q + e) * N + col] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < SMALL_MAX_K / 8; ++j) {
+            if (2 * j < nq) {                                        // wave-uniform
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][e], bv[j][e], acc, 0, 0, 0);
+            }
+        }
+    } else {
+        const int ns = (K + 1) / 2;
+        for (int s0 = 0; s0 < ns; s0 += 16) {
+            float av[16], bv[16];
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int k = 2 * (s0 + s) + kh;
+                const bool ok = k < K;
+                av[s] = (ok && rok) ? a[(long)row * K + k] : 0.f;
+                bv[s] = (ok && cok) ? (BKC ? b[(long)col * K + k] : b[(long)k * N + col]) : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s)
+                if (s0 + s < ns) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s], bv[s], acc, 0, 0, 0);
+        }
+    }
+    if (!cok) return;
+    const float bn = bias ? bias[col] : 0.f;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) {
+        const int m = m0 + 4 * kh + (v & 3) + 8 * (v >> 2);
+        if (m >= M) continue;
+        const long off = (long)m * N + col;
+        float r = acc[v] + bn;
+        if (act == 1) r = r > 0.f ? r : 0.f;
+        else if (act == 2) r = tanhf(r);
+        if (gate) {
+            const float h = gate_src[off];
+            r = gate == 1 ? (h > 0.f ? r : 0.f) : r * (1.f - h * h);
+        }
+        if (accumulate) r += c[off];
+        c[off] = r;
+    }
+}
+static bool small_ok(int M, int N, int K) {
+    static const bool off = getenv("ACKTR_LINEAR_SMALL_OFF") != nullptr;      // tuning / comparison switch
+    return !off && K <= SMALL_MAX_K && N <= SMALL_MAX_N && N > SK_MAX_OUT && M <= SMALL_MAX_M;
+}
+// c[M, N] = epilogue(sum_k a[m, k] * B(n, k)); b_kc: B(n, k) = b[n*K + k], else b[k*N + n]
+static int small_linear(const float* a, const float* b, bool b_kc, const float* bias, const float* gate_src, float* c, int M,
+                        int N, int K, int act, int gate, int accumulate, hipStream_t s) {
+    const bool vec = K % 4 == 0 && (((uintptr_t)a) & 15) == 0 && (!b_kc || (((uintptr_t)b) & 15) == 0);
+    const dim3 grid(cdiv(M, 32), cdiv(N, 32)), block(64);
+    if (vec && b_kc) hipLaunchKernelGGL((small_linear_kernel<true, true>), grid, block, 0, s, a, b, bias, gate_src, c, M, N, K, act, gate, accumulate);
+    else if (vec) hipLaunchKernelGGL((small_linear_kernel<true, false>), grid, block, 0, s, a, b, bias, gate_src, c, M, N, K, act, gate, accumulate);
+    else if (b_kc) hipLaunchKernelGGL((small_linear_kernel<false, true>), grid, block, 0, s, a, b, bias, gate_src, c, M, N, K, act, gate, accumulate);
+    else hipLaunchKernelGGL((small_linear_kernel<false, false>), grid, block, 0, s, a, b, bias, gate_src, c, M, N, K, act, gate, accumulate);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" long acktr_linear_fwd_workspace_bytes(int B, int IN, int OUT) {
     const int ns = fwd_slices(B, IN, OUT, 1L << 40);
     return ns > 1 ? (long)(ns + SLAB_GROUP_EXTRA) * B * OUT * (long)sizeof(float) : 0;
@@ -430,6 +528,7 @@ extern "C" int acktr_linear_fwd_f32(const float* x, const float* w, const float*
         ACKTR_LAUNCH_CHECK();
         return 0;
     }
+    if (small_ok(B, OUT, IN)) return small_linear(x, w, true, bias, nullptr, y, B, OUT, IN, act, 0, 0, s);
     float* ws = (float*)workspace;
     const int ns = (ws && (((uintptr_t)ws | (uintptr_t)y) & 15) == 0)
                        ? fwd_slices(B, IN, OUT, workspace_bytes / (long)sizeof(float)) : 1;
@@ -466,6 +565,8 @@ extern "C" int acktr_linear_dgrad_ex_f32(const float* dy, const float* w, const 
         ACKTR_LAUNCH_CHECK();
         return 0;
     }
+    if (!dx_padded && small_ok(B, IN, OUT))
+        return small_linear(dy, w, false, nullptr, gate_src, dx, B, IN, OUT, 0, gate, accumulate, (hipStream_t)stream);
     RowMajorEpi e = row_major_epi(dx, B, IN, IN);
     e.gate = gate; e.gate_src = gate_src; e.ldg = IN; e.accumulate = accumulate;
     if (dx_padded) {                       // second copy as zero-padded [B, C, OH+2p, OW+2p] planes (interior only)

@@ -51,6 +51,33 @@ def test_discriminator_update_vs_reference(ci):
             assert e <= 1e-4, (it, n, e)
 
 
+class OnlyGenerator(object):
+    """A rollout storage that offers nothing but the reference's generator (storage.py:107): update() then takes the
+    gathered 8-tuples instead of this package's index batches."""
+
+    def __init__(self, rs):
+        self.feed_forward_generator = rs.feed_forward_generator
+
+
+@pytest.mark.parametrize('ci', range(len(GAIL_CASES)))
+def test_discriminator_update_index_batches_equal_gathered_batches(ci):
+    """update() over index batches (gather fused into the first kernel) == update() over gathered tuples, bit for bit,
+    eager and replayed (four updates: two warm steps, capture, replay)."""
+    tag, od, A, hid, B, T, N = GAIL_CASES[ci]
+    out = []
+    for light in (True, False):
+        disc, P, ro, expert = make_disc(ci)
+        rs = make_storage(ro, (od,), Box(A))
+        loader = FixedLoader([(t(s), t(a)) for s, a in expert], B)
+        losses = []
+        for it in range(4):
+            torch.manual_seed(900 + it)
+            losses.append(disc.update(loader, rs if light else OnlyGenerator(rs), obsfilt=lambda x, update=False: x))
+        out.append((losses, disc.flat_params.clone()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+
+
 @pytest.mark.parametrize('ci', range(len(GAIL_CASES)))
 def test_discriminator_gradients_vs_oracle(ci):
     """Both loss terms and every parameter gradient of one minibatch against the oracle's autograd (fp32 CPU)."""
@@ -65,6 +92,28 @@ def test_discriminator_gradients_vs_oracle(ci):
     loss = disc._losses_and_grads(flat_obs.cuda(), flat_act.cuda(), es.cuda(), ea.cuda(), alpha)
     Pg = OrderedDict((k, t(v).clone().requires_grad_(True)) for k, v in P.items())
     gl, gp = gail_ref.disc_losses(Pg, torch.cat([flat_obs, flat_act], 1), torch.cat([es, ea], 1), alpha)
+    (gl + gp).backward()
+    got = loss.cpu().numpy()
+    assert abs(got[0] - gl.item()) <= 1e-4 * abs(gl.item()) and abs(got[1] - gp.item()) <= 1e-4 * abs(gp.item()), (got, gl, gp)
+    for i, (n, p) in enumerate(Pg.items()):
+        e = rel_err(disc._gview(i).cpu().numpy(), p.grad.numpy())
+        assert e <= 1e-4, (n, e)
+
+
+@pytest.mark.parametrize('od,A,hid,B', [(10, 3, 50, 33), (5, 2, 36, 7), (17, 6, 100, 300)])
+def test_discriminator_gradients_odd_shapes_vs_oracle(od, A, hid, B):
+    """Shapes where the row blocks of the stacked [4B, D] operands start at unaligned addresses (odd D, odd B)."""
+    from a2c_ppo_acktr.algo import gail
+    from oracle import gail_ref
+    import synth
+    P = synth.make_params(gail_ref.disc_param_shapes(od + A, hid), 320 + B)
+    disc = gail.Discriminator(od + A, hid, torch.device('cuda'))
+    disc.load_state_dict(OrderedDict((k, t(v)) for k, v in P.items()), strict=True)
+    ps, pa, es, ea = (t(synth.normalish(shp, 800 + i + B)) for i, shp in enumerate(((B, od), (B, A), (B, od), (B, A))))
+    alpha = torch.rand(B, 1, generator=torch.Generator().manual_seed(B))
+    loss = disc._losses_and_grads(ps.cuda(), pa.cuda(), es.cuda(), ea.cuda(), alpha)
+    Pg = OrderedDict((k, t(v).clone().requires_grad_(True)) for k, v in P.items())
+    gl, gp = gail_ref.disc_losses(Pg, torch.cat([ps, pa], 1), torch.cat([es, ea], 1), alpha)
     (gl + gp).backward()
     got = loss.cpu().numpy()
     assert abs(got[0] - gl.item()) <= 1e-4 * abs(gl.item()) and abs(got[1] - gp.item()) <= 1e-4 * abs(gp.item()), (got, gl, gp)

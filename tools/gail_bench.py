@@ -62,7 +62,19 @@ for i, pb in zip(range(nb - 1), gen):
 torch.cuda.synchronize(); t2 = time.perf_counter()
 print('feed_forward_generator: first batch     : %8.1f us (CPU randperm over %d rows)' % ((t1 - t0) * 1e6, T * N))
 print('feed_forward_generator: per later batch : %8.1f us' % ((t2 - t1) / (nb - 1) * 1e6))
+t0 = time.perf_counter()
+for _ in range(3):
+    list(zip(range(nb), rs.minibatch_index_batches(mini_batch_size=128)))
+torch.cuda.synchronize()
+rp = (time.perf_counter() - t0) / 3 * 1e6
+print('minibatch_index_batches, warmed         : %8.1f us per call (randperm + one copy to the device)' % rp)
+t0 = time.perf_counter()
+for _ in range(3):
+    for eb in gail._expert_batches(loader):
+        pass
+print('expert batches, dataset fast path       : %8.1f us per batch' % ((time.perf_counter() - t0) / 3 / nb * 1e6))
 obsfilt = lambda x, update=False: x
 for _ in range(2):
     disc.update(loader, rs, obsfilt)
-print('Discriminator.update, %d batches        : %8.1f us per batch' % (nb, timeit(lambda: disc.update(loader, rs, obsfilt), 4) / nb))
+up = timeit(lambda: disc.update(loader, rs, obsfilt), 4)
+print('Discriminator.update, %d batches        : %8.1f us per batch (%.1f net of the permutation)' % (nb, up / nb, (up - rp) / nb))

@@ -9,7 +9,7 @@ import os
 import torch
 
 from .. import _hip, engine, ops
-from ..parallel import DataParallel
+from ..parallel import DataParallel, PiecewiseGraph
 
 
 class _FlatRMSprop(object):
@@ -69,6 +69,18 @@ class A2C_ACKTR():
         self._graph, self._seen_key, self._loss_acc = None, None, None
         self._kgraphs, self._noise_dev = {}, None
 
+    def _capture(self, rollouts, dev):
+        """One replayable object for _update(): a hipGraph, or under data parallelism graph pieces around the collectives
+        (parallel.PiecewiseGraph; the loss accumulator's all-reduce follows the last piece)."""
+        if self.dp.active:
+            pg = PiecewiseGraph(dev).capture(self.dp, lambda: self._update(rollouts, self._loss_acc))
+            pg.items.append(lambda: self.dp.all_reduce_sum_(self._loss_acc))
+            return pg
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._update(rollouts, self._loss_acc)
+        return g
+
     def _update_acktr_graphed(self, rollouts):
         """ACKTR update with the launch-bound part replayed from a hipGraph: everything except the steps that
         eigendecompose (rocSOLVER's host-driven solver cannot be captured) and the first two (one-off initialisation
@@ -90,12 +102,10 @@ class A2C_ACKTR():
             return self._update(rollouts, None)
         g = self._kgraphs.get(do_stats)
         if g is None:
-            g = torch.cuda.CUDAGraph()
             steps0 = opt.steps
             opt._ext_noise = self._noise_dev
             try:
-                with torch.cuda.graph(g):
-                    self._update(rollouts, self._loss_acc)
+                g = self._capture(rollouts, dev)
             finally:
                 opt._ext_noise = None
                 opt.steps = steps0                  # capture only records: the replay below is this update
@@ -110,7 +120,7 @@ class A2C_ACKTR():
 
     def update(self, rollouts):
         ac = self.actor_critic
-        if self.dp.active or not self.use_graph or ops.profiler is not None:
+        if not self.use_graph or ops.profiler is not None or (self.dp.active and ac.is_recurrent):
             return self._update(rollouts, None)
         if self.acktr:
             return self._update_acktr_graphed(rollouts)
@@ -124,9 +134,7 @@ class A2C_ACKTR():
             self._loss_acc = torch.zeros(3, dtype=torch.float32, device=rollouts.rewards.device)
             return self._update(rollouts, None)
         if self._graph is None:
-            self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
-                self._update(rollouts, self._loss_acc)
+            self._graph = self._capture(rollouts, rollouts.rewards.device)
         self._loss_acc.zero_()
         self._graph.replay()
         vl, al, en = self._loss_acc.tolist()

@@ -337,8 +337,7 @@ class KFACOptimizer(optim.Optimizer):
                 self._cov_dense(None, ptr, ld, B, D, float(Bg), out)
 
         # ---- data-parallel: SUM the sample factors (global scalings already applied), then running averages
-        dp.all_reduce_sum_(self.aa_sample)
-        dp.all_reduce_sum_(self.gg_sample)
+        dp.all_reduce_sum_many_((self.aa_sample, self.gg_sample))
         init = 1 if self.steps == 0 else 0
         for run, smp in ((self.aa_run, self.aa_sample), (self.gg_run, self.gg_sample)):
             d = float(self.stat_decay)

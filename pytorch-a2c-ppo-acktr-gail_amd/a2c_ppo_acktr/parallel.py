@@ -26,6 +26,7 @@ class DataParallel(object):
         # through gloo's own device path (which was seen to hang when two ranks share one GPU, the only way a one-GPU
         # box can rehearse world_size 2).  RCCL ("nccl") reduces the device bucket in place, stream-ordered.
         self._host_staged = dist.is_available() and dist.is_initialized() and dist.get_backend(group) == 'gloo'
+        self._piecewise = None          # a PiecewiseGraph being captured: collectives split it instead of running
 
     @property
     def active(self):
@@ -45,6 +46,9 @@ class DataParallel(object):
     def all_reduce_sum_(self, flat):
         """In-place SUM all-reduce of one flat bucket (gradients, KFAC factors, loss accumulators)."""
         if self.active:
+            if self._piecewise is not None:             # capture records kernels only: the collective becomes an eager
+                self._piecewise.split(lambda: self.all_reduce_sum_(flat))      # step between two graph pieces
+                return flat
             if self._host_staged and flat.is_cuda:
                 host = flat.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -52,6 +56,14 @@ class DataParallel(object):
             else:
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         return flat
+
+    def all_reduce_sum_many_(self, flats):
+        """Consecutive buckets (the two KFAC factor buckets): one eager step between two graph pieces, not an empty piece."""
+        if self.active and self._piecewise is not None:
+            self._piecewise.split(lambda: [self.all_reduce_sum_(f) for f in flats])
+            return
+        for f in flats:
+            self.all_reduce_sum_(f)
 
     def all_reduce_sum_async_(self, flat):
         """Start the SUM all-reduce of a bucket and return a handle whose .wait() orders the current stream after it.
@@ -73,6 +85,67 @@ class DataParallel(object):
             else:
                 dist.broadcast(t, src=src, group=self.group)
         return t
+
+
+class PiecewiseGraph(object):
+    """An update captured as hipGraph pieces with eager steps (the collectives) between them.  RCCL calls cannot be part
+    of a torch-captured graph here (they run on RCCL's own stream behind event edges the capture does not own), and the
+    host-staged gloo form synchronises; so under data parallelism the launch-bound stretches between two collectives are
+    captured one graph each, all from ONE memory pool (a later piece reads what an earlier one wrote), and replay() runs
+    graph, collective, graph, ... in capture order on the current stream.  Capture records only: nothing has run and no
+    collective has been issued when capture() returns."""
+
+    def __init__(self, device):
+        self.device = device
+        self.items = []                 # torch.cuda.CUDAGraph | callable
+        self._pool = None
+        self._cur = None
+        self._stream = None
+
+    def _begin(self):
+        g = torch.cuda.CUDAGraph()
+        if self._pool is None:
+            self._pool = torch.cuda.graph_pool_handle()
+        g.capture_begin(pool=self._pool)
+        self._cur = g
+
+    def _end(self):
+        self._cur.capture_end()
+        self.items.append(self._cur)
+        self._cur = None
+
+    def split(self, fn):
+        """Called from inside capture(): close the current piece, queue `fn` as an eager step, open the next piece."""
+        self._end()
+        self.items.append(fn)
+        self._begin()
+
+    def capture(self, dp, body):
+        import gc
+        torch.cuda.synchronize(self.device)
+        gc.collect()                                    # nothing may be freed by the collector mid-capture
+        cur = torch.cuda.current_stream(self.device)
+        self._stream = torch.cuda.Stream(device=self.device)
+        self._stream.wait_stream(cur)
+        dp._piecewise = self
+        try:
+            with torch.cuda.stream(self._stream):
+                self._begin()
+                try:
+                    body()
+                finally:
+                    self._end()
+        finally:
+            dp._piecewise = None
+        cur.wait_stream(self._stream)
+        return self
+
+    def replay(self):
+        for it in self.items:
+            if isinstance(it, torch.cuda.CUDAGraph):
+                it.replay()
+            else:
+                it()
 
 
 class _Done(object):

@@ -59,15 +59,15 @@ def _worker(rank, world, port, out_dir, algo_name, backend='gloo'):
         agent = algo.PPO(pol, clip_param=0.1, ppo_epoch=2, num_mini_batch=2, value_loss_coef=0.5, entropy_coef=0.01,
                          lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
         n_upd = 3                                        # the third update replays the captured graphs
-    elif algo_name == 'a2c_rec':
+    elif algo_name in ('a2c', 'a2c_rec'):
         rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
         agent = algo.A2C_ACKTR(pol, 0.5, 0.01, lr=7e-4, eps=1e-5, alpha=0.99, max_grad_norm=0.5)
-        n_upd = 2
+        n_upd = 2 if rec else 4                          # feed-forward: updates 2.. replay the graph pieces
     else:
         rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
         agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
         agent.optimizer.Tf = 2
-        n_upd = 3
+        n_upd = 6                                        # updates 3 and 5 replay graph pieces around the collectives
     if backend == 'nccl' and world == 1:                 # one rank, but through the data-parallel code path on RCCL
         from a2c_ppo_acktr.parallel import DataParallel
         agent.dp = DataParallel(force_active=True)
@@ -87,7 +87,7 @@ def _worker(rank, world, port, out_dir, algo_name, backend='gloo'):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'ppo_rec', 'a2c_rec'])
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'a2c', 'ppo_rec', 'a2c_rec'])
 def test_two_rank_update_matches_single_process(tmp_path, algo_name):
     out = str(tmp_path)
     mp.spawn(_worker, args=(1, 0, out, algo_name), nprocs=1, join=True)
@@ -102,7 +102,7 @@ def test_two_rank_update_matches_single_process(tmp_path, algo_name):
     assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err
 
 
-@pytest.mark.parametrize('algo_name', ['ppo', 'acktr'])
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'a2c'])
 def test_rccl_collectives_single_rank(tmp_path, algo_name):
     """The data-parallel code path on the REAL RCCL backend (one rank is all a one-GPU box can host): split graphs,
     the asynchronous late-bucket all-reduce on RCCL's stream, factor / eigen all-reduces.  With one rank every
@@ -118,7 +118,7 @@ def test_rccl_collectives_single_rank(tmp_path, algo_name):
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs two GPUs: two ranks over real RCCL (xGMI)')
-@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'ppo_rec'])
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'a2c', 'ppo_rec'])
 def test_two_rank_update_matches_single_process_rccl(tmp_path, algo_name):
     """The same check with one GPU per rank and the `nccl` (= RCCL) backend: runs wherever the box has two GPUs (the
     driver's multi-GPU node), skips on a one-GPU box.  Exercises what gloo cannot: in-place device all-reduces on RCCL's

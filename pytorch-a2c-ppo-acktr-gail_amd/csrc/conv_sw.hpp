@@ -315,15 +315,24 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
     };
 
     // work items (tile, M group) are dealt round-robin over all waves of the grid: every CU gets the same number of
-    // items +-1 however few there are.  Which wave takes which item: SwGeom::BY_WG (measured per layer: +9 % on the
-    // conv2 forward, +4-8 % on conv3 and the dgrads, -3 % on conv1 whose windows barely overlap)
+    // items +-1 however few there are.  Which wave takes which item in a FULL round: SwGeom::BY_WG (measured per layer:
+    // +9 % on the conv2 forward, +4-8 % on conv3 and the dgrads, -3 % on conv1 whose windows barely overlap).  The last,
+    // partial round is dealt wave-major (wave 0 of every workgroup first, then wave 1, ...): dealt like a full round it
+    // would land on all waves of the first few CUs, whose SIMDs then run two items more than everybody else's (conv2
+    // dgrad at minibatch 1024: 6400 items on 2048 waves -> 8 item-times on 32 CUs against 6 elsewhere; now 7 everywhere).
     const int nitems = ntiles * MG;
     const int item_stride = gridDim.x * G::NWAVES;
     // (not BY_WG) workgroups are dispatched round-robin over the 8 XCDs: renumber them so that consecutive items run
     // on the same XCD and share its L2 (conv1 forward: 72.5 -> 71.1 us)
     const int bx = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
-    int item = G::BY_WG ? blockIdx.x * G::NWAVES + wave : bx + gridDim.x * wave;
-    if (item >= nitems) return;
+    const int slot = G::BY_WG ? blockIdx.x * G::NWAVES + wave : bx + gridDim.x * wave;
+    const int full = nitems / item_stride, rem = nitems - full * item_stride;
+    const int tail_slot = wave * gridDim.x + blockIdx.x;
+    const int my_items = full + (tail_slot < rem ? 1 : 0);
+    if (my_items == 0) return;
+    auto item_of = [&](int k) { return k < full ? k * item_stride + slot : full * item_stride + tail_slot; };
+    int kround = 0;
+    int item = item_of(0);
 
     VT buf[2][NL];
     int r; bool valid;
@@ -340,8 +349,8 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
 #pragma unroll
             for (int g = 0; g < 16; ++g) acc[a][g] = 0.f;
 
-        const int next_item = item + item_stride;
-        const bool has_next = next_item < nitems;
+        const bool has_next = kround + 1 < my_items;
+        const int next_item = has_next ? item_of(kround + 1) : item;
         int r_next = 0; bool valid_next = false;
         const float* base_next = base;
         const int mg_next = has_next ? next_item % MG : mg;
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
         }
         epi.template store<TMW>(r, valid, h, mg, acc);
         if (!has_next) break;
-        item = next_item; base = base_next; r = r_next; valid = valid_next; mg = mg_next;
+        item = next_item; base = base_next; r = r_next; valid = valid_next; mg = mg_next; ++kround;
     }
 }
 

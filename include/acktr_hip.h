@@ -247,7 +247,13 @@ int acktr_kfac_cov_g_conv_f32(const float* dy, int B, int OC, int SP, float alph
  * Linear / AddBias grad_outputs (alpha = B_global, kfac.py:63-64). */
 int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, float alpha, float* out, void* workspace,
                              long workspace_bytes, void* stream);
-/* out[row] = sum_sp g[row, sp] -- the AddBias branch of compute_cov_g, kfac.py:59-61. */
+/* compute_cov_a with fast_cnn=True, kfac.py:33-36: out[B, C*KH*KW] = scale * the mean over the window positions of the
+ * im2col patches of x[B (through gather_idx, may be NULL), C, H, W] -- one mean patch per image; the factor is then
+ * acktr_kfac_cov_dense_f32 of it.  H*W <= 8192, KH*KW <= 256. */
+int acktr_kfac_patch_mean_f32(const float* x, const int64_t* gather_idx, int B, int C, int H, int W, int KH, int KW, int S,
+                              float scale, float* out, void* stream);
+/* out[row] = sum_sp g[row, sp] -- the AddBias branch of compute_cov_g, kfac.py:59-61 (and the Conv2d branch with
+ * fast_cnn=True, kfac.py:53-55). */
 int acktr_spatial_sum_f32(const float* g, int rows, int SP, float* out, void* stream);
 /* update_running_stat -- kfac.py:67-71: m = ((m * c1) + x) * c2, three roundings, with c1 = (float)(d/(1-d)) and
  * c2 = (float)(1-d) evaluated by the host in double like the python scalars; init != 0 first sets m = x

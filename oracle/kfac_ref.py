@@ -33,21 +33,26 @@ def extract_patches(x, k, s):
     return x.view(x.size(0), x.size(1), x.size(2), -1)
 
 
-def cov_a(a, kind, ksize=None, stride=None):
+def cov_a(a, kind, ksize=None, stride=None, fast_cnn=False):
     """kfac.py:29-46."""
     B = a.size(0)
     if kind == 'conv':
         p = extract_patches(a, ksize, stride)
-        a = p.view(-1, p.size(-1)).div(p.size(1)).div(p.size(2))
+        if fast_cnn:                                       # kfac.py:33-36: one mean patch per image
+            a = p.view(p.size(0), -1, p.size(-1)).mean(1)
+        else:
+            a = p.view(-1, p.size(-1)).div(p.size(1)).div(p.size(2))
     elif kind == 'bias':
         a = torch.ones(B, 1, dtype=a.dtype)
     return a.t() @ (a / B)
 
 
-def cov_g(g, kind):
+def cov_g(g, kind, fast_cnn=False):
     """kfac.py:49-64."""
     B = g.size(0)
-    if kind == 'conv':
+    if kind == 'conv' and fast_cnn:                        # kfac.py:53-55: summed over space
+        g = g.view(g.size(0), g.size(1), -1).sum(-1)
+    elif kind == 'conv':
         g = g.permute(0, 2, 3, 1).contiguous()
         g = g.view(-1, g.size(-1)).mul(g.size(1)).mul(g.size(2))
     elif kind == 'bias':
@@ -63,8 +68,9 @@ def running_stat(x, m, decay):
     m *= (1 - decay)
 
 
-def new_state(lr=0.25, momentum=0.9, stat_decay=0.99, kl_clip=0.001, damping=1e-2, weight_decay=0, Ts=1, Tf=10):
-    return dict(steps=0, lr=lr, momentum=momentum, stat_decay=stat_decay, kl_clip=kl_clip, damping=damping,
+def new_state(lr=0.25, momentum=0.9, stat_decay=0.99, kl_clip=0.001, damping=1e-2, weight_decay=0, Ts=1, Tf=10,
+              fast_cnn=False):
+    return dict(fast_cnn=fast_cnn, steps=0, lr=lr, momentum=momentum, stat_decay=stat_decay, kl_clip=kl_clip, damping=damping,
                 weight_decay=weight_decay, Ts=Ts, Tf=Tf, m_aa=OrderedDict(), m_gg=OrderedDict(), Q_a={}, Q_g={},
                 d_a={}, d_g={}, mom={})
 
@@ -145,7 +151,7 @@ def acktr_update(P, st, ro, value_loss_coef, entropy_coef, noise=None):
             a_in = caps[lname][0].detach()
             if kind == 'conv':
                 w = P[pname]
-                aa = cov_a(a_in, 'conv', (w.size(2), w.size(3)), geom[lname][1])
+                aa = cov_a(a_in, 'conv', (w.size(2), w.size(3)), geom[lname][1], st.get('fast_cnn', False))
             else:
                 aa = cov_a(a_in, kind)
             if st['steps'] == 0:
@@ -166,7 +172,7 @@ def acktr_update(P, st, ro, value_loss_coef, entropy_coef, noise=None):
         gouts = torch.autograd.grad(pg_fisher + vf_fisher, outs, retain_graph=True)
         gmap = dict(zip(caps.keys(), gouts))
         for key, kind, pname, lname in mods:
-            gg = cov_g(gmap[lname].detach(), kind)
+            gg = cov_g(gmap[lname].detach(), kind, st.get('fast_cnn', False))
             if st['steps'] == 0:
                 st['m_gg'][key] = gg.clone()
             running_stat(gg, st['m_gg'][key], st['stat_decay'])

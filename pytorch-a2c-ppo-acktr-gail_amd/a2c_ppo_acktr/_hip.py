@@ -113,6 +113,7 @@ _PROTOS = {
     'acktr_kfac_cov_a_conv_f32': (c_i, [c_p, c_p] + [c_i] * 7 + [c_f, c_p, c_p, c_l, c_p]),
     'acktr_kfac_cov_g_conv_f32': (c_i, [c_p, c_i, c_i, c_i, c_f, c_p, c_p, c_l, c_p]),
     'acktr_kfac_cov_dense_f32': (c_i, [c_p, c_l, c_i, c_i, c_f, c_p, c_p, c_l, c_p]),
+    'acktr_kfac_patch_mean_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_p, c_p]),
     'acktr_spatial_sum_f32': (c_i, [c_p, c_i, c_i, c_p, c_p]),
     'acktr_kfac_running_stat_f32': (c_i, [c_p, c_p, c_l, c_f, c_f, c_i, c_p]),
     'acktr_jacobi_max_n': (c_i, []),

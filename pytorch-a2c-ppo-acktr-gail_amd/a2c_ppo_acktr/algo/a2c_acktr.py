@@ -91,7 +91,7 @@ class A2C_ACKTR():
         dev = rollouts.rewards.device
         key = tuple(getattr(rollouts, k).data_ptr() for k in ('obs', 'actions', 'returns')) + \
             (T, N, ac.flat_params.data_ptr(), self.value_loss_coef, self.entropy_coef, opt.lr, opt.Ts, opt.Tf,
-             opt.damping, opt.kl_clip, opt.stat_decay, opt.momentum, opt.weight_decay)
+             opt.damping, opt.kl_clip, opt.stat_decay, opt.momentum, opt.weight_decay, opt.fast_cnn)
         if self._seen_key != key:
             self._seen_key, self._kgraphs = key, {}
             self._loss_acc = torch.zeros(3, dtype=torch.float32, device=dev)

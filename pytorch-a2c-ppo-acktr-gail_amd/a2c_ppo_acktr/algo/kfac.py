@@ -70,8 +70,6 @@ class KFACOptimizer(optim.Optimizer):
 
         super(KFACOptimizer, self).__init__(model.parameters(), defaults)
 
-        if fast_cnn:
-            raise NotImplementedError('fast_cnn=True (kfac.py:33-36,53-55) is never used by the reference driver; not built')
 
         self.known_modules = {'Linear', 'Conv2d', 'AddBias'}
 
@@ -271,6 +269,13 @@ class KFACOptimizer(optim.Optimizer):
                 OC, C, KH, KW = m.param.shape
                 H, W = x.shape[-2], x.shape[-1]
                 OH, OW = (H - KH) // stride + 1, (W - KW) // stride + 1
+                if self.fast_cnn:                                   # kfac.py:33-36: one mean patch per image
+                    pm = torch.empty(B, C * KH * KW, dtype=f32, device=dev)
+                    rc = L.acktr_kfac_patch_mean_f32(_hip.dev_ptr(x), _hip.dev_ptr(idx, torch.int64), B, C, H, W, KH, KW,
+                                                     stride, sc, _hip.dev_ptr(pm), stream)
+                    _hip.check(rc, 'acktr_kfac_patch_mean_f32')
+                    self._cov_dense(pm, pm.data_ptr(), C * KH * KW, B, C * KH * KW, 1.0 / Bg, out)
+                    continue
                 alpha = (sc * sc) / (float(Bg) * float(OH * OW) ** 2)
                 ws = ops.workspace(dev, L.acktr_kfac_cov_workspace_bytes(C * KH * KW, B * OH * OW), 'kfac')
                 D_, R_ = C * KH * KW, B * OH * OW           # symmetric-half flop count R D (D+1), SURVEY 8(d)
@@ -322,12 +327,12 @@ class KFACOptimizer(optim.Optimizer):
             if m.layer in conv_g:
                 dy = conv_g[m.layer]
                 OC, SP = dy.shape[1], dy.shape[2] * dy.shape[3]
-                if m.kind == 'Conv2d':
+                if m.kind == 'Conv2d' and not self.fast_cnn:
                     ws = ops.workspace(dev, L.acktr_kfac_cov_workspace_bytes(OC, B * SP), 'kfac')
                     rc = L.acktr_kfac_cov_g_conv_f32(_hip.dev_ptr(dy), B, OC, SP, float(SP) * Bg, _hip.dev_ptr(out),
                                                      _hip.dev_ptr(ws), ws.numel(), stream)
                     _hip.check(rc, 'acktr_kfac_cov_g_conv_f32')
-                else:                                              # AddBias after a conv: sum over space first
+                else:                              # AddBias after a conv (and Conv2d with fast_cnn): sum over space first
                     ssum = torch.empty(B, OC, dtype=f32, device=dev)
                     rc = L.acktr_spatial_sum_f32(_hip.dev_ptr(dy), B * OC, SP, _hip.dev_ptr(ssum), stream)
                     _hip.check(rc, 'acktr_spatial_sum_f32')

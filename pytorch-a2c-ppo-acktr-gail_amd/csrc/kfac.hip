@@ -434,6 +434,48 @@ extern "C" int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, 
     return rc ? rc : launch_symmetrize_lower(out, D, s);
 }
 
+// fast_cnn statistics (kfac.py:33-36): out[b, (c, ky, kx)] = scale * mean over the OH x OW window positions of
+// x[img(b), c, S*oy + ky, S*ox + kx] -- one mean patch per image.  One workgroup per (image, channel): the plane goes
+// through LDS once, thread (part, tap) sums every `parts`-th window position of its tap, the parts are added in order.
+__global__ __launch_bounds__(256) void patch_mean_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx, int C,
+                                                         int H, int W, int KH, int KW, int S, float scale,
+                                                         float* __restrict__ out) {
+    extern __shared__ float pm_smem[];
+    const int b = blockIdx.x / C, c = blockIdx.x % C;
+    const long img = idx ? (long)idx[b] : (long)b;
+    const float* plane = x + (img * C + c) * (long)H * W;
+    const int OH = (H - KH) / S + 1, OW = (W - KW) / S + 1, taps = KH * KW, parts = 256 / taps;
+    float* part_sum = pm_smem + H * W;
+    for (int i = threadIdx.x; i < H * W; i += 256) pm_smem[i] = plane[i];
+    __syncthreads();
+    const int tap = threadIdx.x % taps, part = threadIdx.x / taps;
+    if (part < parts) {
+        const int ky = tap / KW, kx = tap % KW;
+        float s = 0.f;
+        for (int p = part; p < OH * OW; p += parts) s += pm_smem[((p / OW) * S + ky) * W + (p % OW) * S + kx];
+        part_sum[part * taps + tap] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < taps) {
+        float s = 0.f;
+        for (int q = 0; q < parts; ++q) s += part_sum[q * taps + threadIdx.x];
+        out[((long)b * C + c) * taps + threadIdx.x] = scale * (s / (float)(OH * OW));
+    }
+}
+
+extern "C" int acktr_kfac_patch_mean_f32(const float* x, const int64_t* gather_idx, int B, int C, int H, int W, int KH, int KW,
+                                         int S, float scale, float* out, void* stream) {
+    ACKTR_ARG(x && out && B > 0 && C > 0, "kfac_patch_mean: bad arguments");
+    ACKTR_ARG(KH > 0 && KW > 0 && S > 0 && KH <= H && KW <= W && KH * KW <= 256 && (long)H * W <= 8192,
+              "kfac_patch_mean: unsupported geometry %dx%d k%dx%d s%d", H, W, KH, KW, S);
+    ACKTR_ARG((long)B * C < (1L << 31), "kfac_patch_mean: too many planes");
+    const size_t lds = ((size_t)H * W + 256) * sizeof(float);
+    hipLaunchKernelGGL(patch_mean_kernel, dim3(B * C), dim3(256), lds, (hipStream_t)stream, x, gather_idx, C, H, W, KH, KW, S,
+                       scale, out);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int acktr_spatial_sum_f32(const float* g, int rows, int SP, float* out, void* stream) {
     ACKTR_ARG(g && out && rows > 0 && SP > 0, "spatial_sum: bad arguments");
     hipLaunchKernelGGL(spatial_sum_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, g, rows, SP, out);

@@ -8,14 +8,18 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def main():
+def main(fast=False):
+    """fast=False: kfac.npz (cases 0, 1).  fast=True: kfac_fast.npz, case 2 = the NatureCNN case with the optimizer's
+    public `fast_cnn` attribute (kfac.py:98, read by the hooks at kfac.py:150,168) set to True."""
     import make_golden as mg          # installs the reference import harness
     import synth
     import ref_harness
     from a2c_ppo_acktr import algo    # reference
     out = {}
-    cases = [('cnn', 'cnn', None, 6, 20, 32), ('mlp', 'mlp', 17, 6, 5, 16)]
+    cases = [('cnn', 'cnn', None, 6, 20, 32), ('mlp', 'mlp', 17, 6, 5, 16), ('cnn_fast', 'cnn', None, 6, 20, 32)]
     for ci, (tag, kind, od, A, T, N) in enumerate(cases):
+        if fast != tag.endswith('_fast'):
+            continue
         pol, P = mg.make_policy(kind, 90 + ci, od, A)
         obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
         space = ref_harness.Discrete(A) if kind == 'cnn' else ref_harness.Box(A)
@@ -24,6 +28,8 @@ def main():
         rs.compute_returns(mg.t(ro['next_value']), False, 0.99, 0.95, False)
         agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
         agent.optimizer.Tf = 2            # public attribute (kfac.py:137): eigendecompose at steps 0 and 2
+        if fast:
+            agent.optimizer.fast_cnn = True
         names = [n for n, _ in pol.named_parameters()]
         out[tag + '/param_names'] = np.array(names)
         for it in range(3):
@@ -39,9 +45,9 @@ def main():
                     mg.summarize(tag + '/update%d/%s/%d' % (it, fam, i), mat, out)
                     out[tag + '/update%d/%s/%d#trace' % (it, fam, i)] = np.float64(np.trace(mat.astype(np.float64)))
         out[tag + '/module_classes'] = np.array([m.__class__.__name__ for m in agent.optimizer.modules])
-    np.savez_compressed(os.path.join(HERE, 'kfac.npz'), **out)
+    np.savez_compressed(os.path.join(HERE, 'kfac_fast.npz' if fast else 'kfac.npz'), **out)
 
 
 if __name__ == '__main__':
     sys.path.insert(0, HERE)
-    main()
+    main(fast='--fast' in sys.argv)

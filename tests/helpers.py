@@ -141,7 +141,12 @@ def golden_subset(G, prefix, arr):
     return G[prefix + '#sample'].astype(np.float64), a[::SAMPLE_STRIDE].astype(np.float64)
 
 
-KFAC_CASES = [('cnn', 'cnn', None, 6, 20, 32), ('mlp', 'mlp', 17, 6, 5, 16)]
+KFAC_CASES = [('cnn', 'cnn', None, 6, 20, 32), ('mlp', 'mlp', 17, 6, 5, 16),
+              ('cnn_fast', 'cnn', None, 6, 20, 32)]          # tag *_fast: KFACOptimizer.fast_cnn = True (kfac.py:33-36,53-55)
+
+
+def kfac_golden(tag):
+    return golden('kfac_fast' if tag.endswith('_fast') else 'kfac')
 
 
 def unsplit_name(n):

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 import synth
-from helpers import KFAC_CASES, check_summary, golden, t, unsplit_name, update_vector_errors
+from helpers import KFAC_CASES, check_summary, golden, kfac_golden, t, unsplit_name, update_vector_errors
 from oracle import kfac_ref
 from test_policy_gpu import Box, Discrete, make_policy, make_storage
 
@@ -226,6 +226,25 @@ def test_precondition_vs_torch(OUT, IN):
     assert rel(v.cpu().numpy(), ref.numpy()) < 5e-5
 
 
+@pytest.mark.parametrize('H,K,S,C,B', [(84, 8, 4, 4, 5), (20, 4, 2, 32, 7), (9, 3, 1, 64, 3), (12, 5, 3, 2, 4)])
+def test_patch_mean_vs_torch(H, K, S, C, B):
+    """acktr_kfac_patch_mean_f32 (compute_cov_a with fast_cnn=True, kfac.py:33-36) against unfold + mean, with and
+    without a gather index."""
+    from a2c_ppo_acktr import _hip
+    g = torch.Generator().manual_seed(H + B)
+    x = torch.rand(B + 3, C, H, H, generator=g)
+    idx = torch.tensor([(3 * i + 1) % (B + 3) for i in range(B)], dtype=torch.int64)
+    for use_idx in (False, True):
+        xs = x[idx] if use_idx else x[:B]
+        p = xs.double().unfold(2, K, S).unfold(3, K, S).permute(0, 2, 3, 1, 4, 5).contiguous()
+        ref = (p.view(B, -1, C * K * K).mean(1) * 0.25).float()
+        out = torch.empty(B, C * K * K, device='cuda')
+        rc = _hip.lib().acktr_kfac_patch_mean_f32(_hip.dev_ptr(x.cuda()), _hip.dev_ptr(idx.cuda()) if use_idx else None, B, C, H,
+                                                 H, K, K, S, 0.25, _hip.dev_ptr(out), _hip.cur_stream())
+        _hip.check(rc, 'patch_mean')
+        assert rel(out.cpu().numpy(), ref.numpy()) < 2e-6
+
+
 def test_precondition_batched_vs_torch():
     """acktr_kfac_precondition_batched_f32: every layer shape class of the two policies in ONE call (16-byte and scalar
     load groups, 1-column bias modules, 1- and 6-row heads, more jobs than one group holds) against torch fp64."""
@@ -265,7 +284,7 @@ def test_acktr_update_vs_reference(ci):
     from a2c_ppo_acktr import algo
     from test_oracle_kfac import fp64_truth
     tag, kind, od, A, T, N = KFAC_CASES[ci]
-    G = golden('kfac')
+    G = kfac_golden(tag)
     pol = make_policy(kind, od, A, 90 + ci)
     obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
     ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=820 + ci)
@@ -274,6 +293,7 @@ def test_acktr_update_vs_reference(ci):
     truth = fp64_truth(ci)
     agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
     agent.optimizer.Tf = 2
+    agent.optimizer.fast_cnn = tag.endswith('_fast')       # public attribute, as the golden harness sets it (kfac.py:134)
     names = [str(n) for n in G[tag + '/param_names']]
     assert [n for n, _ in pol.named_parameters()] == names, 'split_bias must rename parameters like the reference'
     assert [m.__class__.__name__ for m in agent.optimizer.modules] == [str(c) for c in G[tag + '/module_classes']]
@@ -323,6 +343,7 @@ def test_acktr_graph_replay_matches_eager(ci):
         rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
         agent = algo.A2C_ACKTR(pol, value_loss_coef=0.5, entropy_coef=0.01, acktr=True)
         agent.use_graph = use_graph
+        agent.optimizer.fast_cnn = tag.endswith('_fast')
         agent.optimizer.Tf = 4                       # eig at optimizer steps 0 and 4; replays at 2, 3, 5, 6
         agent.optimizer.lr = 0.02                    # keep seven updates on one rollout well behaved
         torch.manual_seed(77)

@@ -14,7 +14,7 @@ import pytest
 import torch
 
 import synth
-from helpers import (KFAC_CASES, check_summary, golden, params_torch, shapes_for, t, unsplit_name,
+from helpers import (KFAC_CASES, check_summary, kfac_golden, params_torch, shapes_for, t, unsplit_name,
                      update_vector_errors)
 from oracle import kfac_ref, returns_ref
 
@@ -35,7 +35,7 @@ def fp64_truth(ci, n_updates=3):
     P, ro = kfac_inputs(ci)
     P64 = OrderedDict((k, v.double()) for k, v in P.items())
     ro64 = {k: (t(v).double() if v.dtype == np.float32 else t(v)) for k, v in ro.items()}
-    st = kfac_ref.new_state(Tf=2)
+    st = kfac_ref.new_state(Tf=2, fast_cnn=tag.endswith('_fast'))
     out = []
     for it in range(n_updates):
         torch.manual_seed(555 + it)
@@ -50,11 +50,11 @@ def fp64_truth(ci, n_updates=3):
 @pytest.mark.parametrize('ci', range(len(KFAC_CASES)))
 def test_acktr_update_oracle_vs_reference(ci):
     tag, kind, od, A, T, N = KFAC_CASES[ci]
-    G = golden('kfac')
+    G = kfac_golden(tag)
     P, ro = kfac_inputs(ci)
     ro = {k: t(v) for k, v in ro.items()}
     truth = fp64_truth(ci)
-    st = kfac_ref.new_state(Tf=2)
+    st = kfac_ref.new_state(Tf=2, fast_cnn=tag.endswith('_fast'))
     mods = kfac_ref.module_list(P)
     assert len(mods) == len(G[tag + '/module_classes'])
     names = [str(n) for n in G[tag + '/param_names']]

@@ -138,7 +138,7 @@ class PPO():
         else:
             self.optimizer.step(self.max_grad_norm, capturing=capturing)
 
-    def _dp_step(self, b, split, graphs):
+    def _dp_step(self, b, split, graphs, capturing=False):
         """One data-parallel minibatch step: (phase 1) -> start all-reduce of grads[split:] -> (phase 2) -> all-reduce
         of grads[:split] -> optimiser; without a split, one all-reduce of the whole bucket after the backward."""
         ac = self.actor_critic
@@ -156,7 +156,7 @@ class PPO():
             graphs[2].replay()
             self.optimizer.step_count += 1
         else:
-            self.optimizer.step(self.max_grad_norm)                                    # ppo.py:82-84
+            self.optimizer.step(self.max_grad_norm, capturing=capturing)               # ppo.py:82-84
 
     def update(self, rollouts):
         ac = self.actor_critic
@@ -191,19 +191,27 @@ class PPO():
                 # overlapped buckets run launch by launch: replaying the three graph pieces around the two
                 # collectives measured 13.2 ms per update against 11.9 eager (and 11.8 for two graphs around ONE
                 # un-overlapped all-reduce, which then pays the whole transfer on the critical path)
-                graph_ok = graph_ok and os.environ.get('ACKTR_DP_GRAPH', '0') == '1'
+                graph_ok = graph_ok and os.environ.get('ACKTR_DP_GRAPH', '0') in ('1', 'full')
+            # ACKTR_DP_GRAPH=full (RCCL only, opt-in): the collectives are captured too -- torch records an RCCL all-reduce
+            # into the graph as a branch on RCCL's stream (tools/rccl_graph_probe.py) -- so a data-parallel epoch is ONE
+            # graph like the single-process one, overlap included.  Rehearsed with one rank only; not the default until a
+            # multi-GPU box has replayed it.
+            full = (self.dp.active and os.environ.get('ACKTR_DP_GRAPH', '0') == 'full' and not self.dp._host_staged)
             # Single process: ONE graph per epoch; step k reads its rows from slice k of a device buffer that receives the
             # whole epoch's permutation in one copy -- a 512-byte host-to-device copy between
             # every two replays cost 4.4 us of device time plus an exposed graph-launch latency per step (10 % of the
             # 44 us MLP step).  Data-parallel: the all-reduce sits between two graphs that read `self._idx`.
-            per_pos = graph_ok and not self.dp.active
+            per_pos = graph_ok and (not self.dp.active or full)
             if graph_ok and self._graphs is None:           # capture (records only; executes nothing)
                 if per_pos:
                     self._idx_all = torch.zeros(self.num_mini_batch, hi - lo, dtype=torch.int64, device=dev)
                     g = torch.cuda.CUDAGraph()              # the whole epoch: num_mini_batch steps back to back
                     with torch.cuda.graph(g):
                         for k in range(self.num_mini_batch):
-                            self._step(dict(b, idx=self._idx_all[k]), capturing=True)
+                            if self.dp.active:
+                                self._dp_step(dict(b, idx=self._idx_all[k]), split, None, capturing=True)
+                            else:
+                                self._step(dict(b, idx=self._idx_all[k]), capturing=True)
                             self.optimizer.step_count -= 1
                     self._graphs = (g,)
                 else:                                       # the all-reduce(s) sit between the graphs

@@ -46,6 +46,9 @@ def _worker(rank, world, port, out_dir, algo_name, backend='gloo'):
     from a2c_ppo_acktr.model import Policy
     T, N, A = 6, 12, 6                                   # 72 samples: minibatches of 36 -> shards of 18
     torch.manual_seed(3)
+    if algo_name == 'ppo_fullgraph':                     # the collectives captured into the epoch graph (opt-in mode)
+        os.environ['ACKTR_DP_GRAPH'] = 'full'
+        algo_name = 'ppo'
     rec = algo_name.endswith('_rec')                     # recurrent: ranks split the ENVS of a minibatch
     pol = Policy((4, 84, 84), Discrete(A), base_kwargs={'recurrent': rec})
     pol.to('cuda')
@@ -102,16 +105,17 @@ def test_two_rank_update_matches_single_process(tmp_path, algo_name):
     assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err
 
 
-@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'a2c'])
+@pytest.mark.parametrize('algo_name', ['ppo', 'acktr', 'a2c', 'ppo_fullgraph'])
 def test_rccl_collectives_single_rank(tmp_path, algo_name):
     """The data-parallel code path on the REAL RCCL backend (one rank is all a one-GPU box can host): split graphs,
     the asynchronous late-bucket all-reduce on RCCL's stream, factor / eigen all-reduces.  With one rank every
     collective is an identity, so the result must equal the plain single-process update."""
     out = str(tmp_path)
-    mp.spawn(_worker, args=(1, 0, out, algo_name), nprocs=1, join=True)
+    base = 'ppo' if algo_name == 'ppo_fullgraph' else algo_name
+    mp.spawn(_worker, args=(1, 0, out, base), nprocs=1, join=True)
     mp.spawn(_worker, args=(1, _free_port(), out, algo_name, 'nccl'), nprocs=1, join=True)
-    one = torch.load(os.path.join(out, '%s_w1.pt' % algo_name))
-    two = torch.load(os.path.join(out, '%s_w1_rccl.pt' % algo_name))
+    one = torch.load(os.path.join(out, '%s_w1.pt' % base))
+    two = torch.load(os.path.join(out, '%s_w1_rccl.pt' % base))
     np.testing.assert_allclose(two['losses'].numpy(), one['losses'].numpy(), rtol=2e-4, atol=1e-6)
     err = float((two['flat'] - one['flat']).norm() / one['flat'].norm())
     assert err < (1e-3 if algo_name == 'acktr' else 2e-5), err

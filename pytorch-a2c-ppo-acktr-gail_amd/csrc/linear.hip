@@ -578,6 +578,164 @@ extern "C" int acktr_linear_dgrad_ex_f32(const float* dy, const float* w, const 
     return gemm_rowmajor(dy, OUT, 1, w, 1, IN, e, B, IN, OUT, 1, (hipStream_t)stream);
 }
 
+// ==========================================================================================
+// Weight gradient of a mid-size layer whose 64x64 output tiles number about one per CU (the policy's 1568 -> 512 FC
+// layer: 8 x 25 tiles): dW[o, i] = sum_b dY[b, o] X[b, i], db[o] = sum_b dY[b, o].  Both operands are contiguous along
+// the OUTPUT indices, so the MFMA operands of a 32x32x2 step are plain coalesced dword loads (lane (li, kh): row
+// b = 2s + kh, column o0 + li / i0 + li) -- no LDS staging, no barrier in the K loop.  One workgroup per tile, its eight
+// waves split the batch rows eight ways (the tile GEMM at 200 tiles either ran one 4-wave workgroup per CU over the
+// whole K, or paid a slab round trip for split K), partial tiles meet in LDS and are added in wave order.
+// ==========================================================================================
+constexpr int FW_WAVES = 8, FW_LDS_BYTES = FW_WAVES * 64 * 64 * 4;
+// V2 (OUT and IN even, 8-byte aligned operands): a lane loads TWO adjacent outputs with one 8-byte load and the two 32-wide
+// MFMA blocks of a tile side are interleaved (block a = outputs m0 + 2i + a): half the load instructions per MFMA -- with
+// dword loads the kernel ran at the same ~48 TFLOP/s for 1024 and for 8192 batch rows, paced by load issue, not by the MFMAs.
+template <bool V2>
+__global__ __launch_bounds__(64 * FW_WAVES) void fc_wgrad_sa_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                      float* __restrict__ dw, float* __restrict__ db, int B,
+                                                                      int IN, int OUT, int tiles_n) {
+    typedef float fw2 __attribute__((ext_vector_type(2)));
+    typedef fw2 fw2u __attribute__((aligned(8)));
+    extern __shared__ __attribute__((aligned(16))) float fw_smem[];            // [wave][blk 4][reg 16][lane 64]
+    // workgroups go round-robin over the 8 XCDs: XCD j takes the column tiles j, j+8, ... of every row tile, so its L2 keeps
+    // 1/8 of X next to all of dY (X + dY = 8.4 MB for the policy's FC layer against 4 MB of L2 per XCD)
+    const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3, slots = (tiles_n + 7) >> 3;
+    const int nt = xcd + 8 * (local % slots);
+    if (nt >= tiles_n) return;                                                  // (uniform: before any barrier)
+    const int m0 = (local / slots) * 64, n0 = nt * 64;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+    const int per = ((B + 2 * FW_WAVES - 1) / (2 * FW_WAVES)) * 2;              // rows per wave, even
+    const int k0 = wave * per, k1 = min(B, k0 + per);
+    // column of block a held by this lane: V2: m0 + 2 li + a, else m0 + 32 a + li
+    const int mc0 = V2 ? m0 + 2 * li : m0 + li, mc1 = V2 ? mc0 + 1 : mc0 + 32;
+    const int nc0 = V2 ? n0 + 2 * li : n0 + li, nc1 = V2 ? nc0 + 1 : nc0 + 32;
+    const bool mok0 = mc0 < OUT, mok1 = mc1 < OUT, nok0 = nc0 < IN, nok1 = nc1 < IN;
+    const float* ap = dy + mc0;
+    const float* xp = x + nc0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    float bs0 = 0.f, bs1 = 0.f;
+    constexpr int U = 8;                                                        // k pairs per register block
+    float av[2][U][2], xv[2][U][2];
+    auto load_blk = [&](int buf, int k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k + 2 * u + kh;
+            const bool ok = kk < k1;
+            const long ra = (long)(ok ? kk : 0) * OUT, rx = (long)(ok ? kk : 0) * IN;
+            if constexpr (V2) {                                                 // (pairs are whole: OUT, IN, m0, n0 even)
+                const fw2 a2 = (ok && mok0) ? *reinterpret_cast<const fw2u*>(ap + ra) : fw2{0.f, 0.f};
+                const fw2 x2 = (ok && nok0) ? *reinterpret_cast<const fw2u*>(xp + rx) : fw2{0.f, 0.f};
+                av[buf][u][0] = a2[0]; av[buf][u][1] = a2[1];
+                xv[buf][u][0] = x2[0]; xv[buf][u][1] = x2[1];
+            } else {
+                av[buf][u][0] = (ok && mok0) ? ap[ra] : 0.f;
+                av[buf][u][1] = (ok && mok1) ? ap[ra + 32] : 0.f;
+                xv[buf][u][0] = (ok && nok0) ? xp[rx] : 0.f;
+                xv[buf][u][1] = (ok && nok1) ? xp[rx + 32] : 0.f;
+            }
+        }
+    };
+    auto mul_blk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            bs0 += av[buf][u][0];
+            bs1 += av[buf][u][1];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][a], xv[buf][u][b], acc[a][b], 0, 0, 0);
+        }
+    };
+    if (k0 < k1) {
+        load_blk(0, k0);
+        for (int k = k0; k < k1; k += 4 * U) {                                  // two register blocks per trip: static indices
+            load_blk(1, k + 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_blk(0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_blk(0, k + 4 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_blk(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* mine = fw_smem + (long)wave * 4096;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) mine[((a * 2 + b) * 16 + v) * 64 + lane] = acc[a][b][v];
+    __shared__ float bsum[FW_WAVES][2][64];
+    bsum[wave][0][lane] = bs0;
+    bsum[wave][1][lane] = bs1;
+    __syncthreads();
+    // the eight partial tiles added in wave order; accumulator (a, b, v, l) is row i = 4 (l/32) + (v&3) + 8 (v>>2), column
+    // j = l%32 of block (a, b)
+    if constexpr (V2) {
+        for (int e = threadIdx.x; e < 2048; e += 64 * FW_WAVES) {              // (a, v, l): both b of a lane, one 8-byte store
+            const int a = e >> 10, v = (e >> 6) & 15, l = e & 63;
+            fw2 sum = fw2{0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < FW_WAVES; ++w) {
+                sum[0] += fw_smem[w * 4096 + ((a * 2 + 0) * 16 + v) * 64 + l];
+                sum[1] += fw_smem[w * 4096 + ((a * 2 + 1) * 16 + v) * 64 + l];
+            }
+            const int m = m0 + 2 * (4 * (l >> 5) + (v & 3) + 8 * (v >> 2)) + a, n = n0 + 2 * (l & 31);
+            if (m < OUT && n < IN) *reinterpret_cast<fw2u*>(dw + (long)m * IN + n) = sum;
+        }
+    } else {
+        for (int e = threadIdx.x; e < 4096; e += 64 * FW_WAVES) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < FW_WAVES; ++w) sum += fw_smem[w * 4096 + e];
+            const int blk = e >> 10, v = (e >> 6) & 15, l = e & 63;
+            const int m = m0 + 32 * (blk >> 1) + 4 * (l >> 5) + (v & 3) + 8 * (v >> 2), n = n0 + 32 * (blk & 1) + (l & 31);
+            if (m < OUT && n < IN) dw[(long)m * IN + n] = sum;
+        }
+    }
+    if (db && n0 == 0 && threadIdx.x < 64) {                                    // both k halves of a lane, eight waves
+        const int a = threadIdx.x >> 5, l = threadIdx.x & 31;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < FW_WAVES; ++w) sum += bsum[w][a][l] + bsum[w][a][l + 32];
+        const int m = V2 ? m0 + 2 * l + a : m0 + 32 * a + l;
+        if (m < OUT) db[m] = sum;
+    }
+}
+namespace acktr { int sw_num_cus(); }
+static bool fc_wgrad_sa_ok(int B, int IN, int OUT) {
+    static const bool off = getenv("ACKTR_FC_WGRAD_TILE") != nullptr;          // tuning / comparison switch
+    const long tiles = (long)cdiv(OUT, 64) * cdiv(IN, 64);
+    return !off && B >= 256 && B <= 4096 && OUT > SK_MAX_OUT && tiles >= 128 && tiles <= 2L * sw_num_cus();   // (B = 8192: the tile GEMM's long K loop is 0.3 % ahead)
+}
+template <bool V2>
+static int fc_wgrad_sa_t(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT, hipStream_t s) {
+    static bool attr_set = false;                                               // per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_wgrad_sa_kernel<V2>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, FW_LDS_BYTES);
+        if (e != hipSuccess) { set_error("fc_wgrad_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    const int tn = cdiv(IN, 64);
+    hipLaunchKernelGGL((fc_wgrad_sa_kernel<V2>), dim3(cdiv(OUT, 64) * cdiv(tn, 8) * 8), dim3(64 * FW_WAVES), FW_LDS_BYTES, s, dy,
+                       x, dw, db, B, IN, OUT, tn);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+static int fc_wgrad_sa(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT, hipStream_t s) {
+    const bool v2 = OUT % 2 == 0 && IN % 2 == 0 && ((((uintptr_t)dy) | ((uintptr_t)x) | ((uintptr_t)dw)) & 7) == 0;
+    return v2 ? fc_wgrad_sa_t<true>(dy, x, dw, db, B, IN, OUT, s) : fc_wgrad_sa_t<false>(dy, x, dw, db, B, IN, OUT, s);
+}
+
 extern "C" long acktr_linear_wgrad_workspace_bytes(int B, int IN, int OUT) {
     if (OUT <= SK_MAX_OUT && IN % 4 == 0) {
         const long nsl = skinny_slices(B) + SLAB_GROUP_EXTRA;
@@ -615,6 +773,7 @@ extern "C" int acktr_linear_wgrad_f32(const float* dy, const float* x, float* dw
             return 0;
         }
     }
+    if (fc_wgrad_sa_ok(B, IN, OUT)) return fc_wgrad_sa(dy, x, dw, db, B, IN, OUT, s);
     // dW[o, i] = sum_b dY[b, o] * X[b, i] : A(m=o, k=b) = dy[b*OUT + o], B(n=i, k=b) = x[b*IN + i];
     // db[o] = sum_b dY[b, o] is the GEMM's M-operand row sum.  Slab layout [OUT*IN | OUT padded to 4] per K slice.
     const long wk = (long)OUT * IN, slab = wk + (OUT + 3) / 4 * 4;

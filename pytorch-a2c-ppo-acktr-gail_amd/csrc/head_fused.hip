@@ -19,7 +19,7 @@ namespace acktr {
 typedef float hf4 __attribute__((ext_vector_type(4)));
 constexpr int HS_OUT = 8;          // 1 + A <= 8
 constexpr int HS_H = 512;          // hidden size (model.py:173 default)
-constexpr int HS_RPW = 4;          // rows a wave has in flight
+constexpr int HS_RPW = 2;          // rows a wave has in flight (minibatch 1024: 2 -> 128 workgroups, 11.2 us; 4 -> 64, 13.2 us)
 constexpr int HS_WAVES = 4;
 constexpr int HS_ROWS = HS_RPW * HS_WAVES;
 constexpr int HS_TAIL = 12;        // per-slab tail: 8 bias sums, value loss, action loss, entropy, pad

@@ -88,7 +88,9 @@ def test_conv_wgrad_large_batch_split_k_deterministic():
 @pytest.mark.parametrize('B,IN,OUT', [(1, 11, 64), (64, 64, 64), (80, 1568, 512), (256, 512, 7), (1000, 1568, 512),
                                       (64, 64, 3), (130, 17, 64), (33, 512, 1),
                                       # the stationary-accumulator weight gradient (128..512 tiles of 64x64, B >= 256):
-                                      (1024, 1568, 512), (301, 1499, 501), (257, 700, 770)])
+                                      (1024, 1568, 512), (301, 1499, 501), (257, 700, 770),
+                                      # the in-workgroup split-K forward (128..512 tiles of 64x32, IN % 4 == 0, IN >= 512):
+                                      (1000, 1564, 500), (513, 516, 300)])
 @pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
 def test_linear_fwd_bwd(B, IN, OUT, act):
     from a2c_ppo_acktr import ops

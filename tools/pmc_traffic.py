@@ -11,7 +11,7 @@ OPS = [('conv8s4_fwd', 'SwGeom<8, 8, 4, 84, 84, 4,'), ('conv4s2_fwd', 'SwGeom<4,
        ('conv4s2_dgrad', 'SwGeom<2, 2, 1, 11, 11, 64,'), ('conv8s4_wgrad', 'conv1_wgrad_sa_kernel'),
        ('conv4s2_wgrad', 'conv2_wgrad_sa_kernel'), ('conv3s1_wgrad', 'conv3_wgrad_sa_kernel'),
        ('linear1568x512_fwd', 'DenseKCT<true>, acktr::DenseKCT<true>'),
-       ('linear1568x512_wgrad', 'DenseRCT<true>, acktr::DenseRCT<true>'),
+       ('linear1568x512_wgrad', 'fc_wgrad_sa_kernel'),
        ('linear1568x512_dgrad', 'DenseKCT<true>, acktr::DenseRCT<true>')]
 f = {r['kernel']: r for r in csv.DictReader(open(sys.argv[1]))}
 w = {r['kernel']: r for r in csv.DictReader(open(sys.argv[2]))}

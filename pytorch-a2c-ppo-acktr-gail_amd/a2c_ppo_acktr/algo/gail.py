@@ -118,7 +118,7 @@ class Discriminator(nn.Module):
         Ds, Da = policy_state.shape[1], policy_action.shape[1]
         B = policy_state.shape[0] if policy_idx is None else policy_idx.numel()
         D, H = Ds + Da, W1.shape[0]
-        c = lambda t_: t_.to(device=dev, dtype=f32).contiguous()
+        c = lambda x_: x_.to(device=dev, dtype=f32).contiguous()
         ps, pa, es, ea, al = c(policy_state), c(policy_action), c(expert_state), c(expert_action), c(alpha).view(-1)
         assert es.shape == (B, Ds) and ea.shape == (B, Da) and al.numel() == B, 'expert / policy batch shapes differ'
         e = lambda *s: torch.empty(*s, dtype=f32, device=dev)
@@ -170,7 +170,7 @@ class Discriminator(nn.Module):
 
     # ------------------------------------------------------------------ one optimiser step, replayed from a hipGraph
     def _step(self, policy_state, policy_action, expert_state, expert_action, alpha, policy_idx=None):
-        """losses + gradients + Adam for one minibatch (gail.py:67-93).  The ~45 launches of a step are latency-bound,
+        """losses + gradients + Adam for one minibatch (gail.py:67-93).  The 20 launches of a step are latency-bound,
         so from the third step of a given batch shape on they are replayed from a captured hipGraph whose inputs are
         persistent buffers refilled before every replay (ACKTR_HIP_GRAPH=0 disables it).  With `policy_idx` the policy
         operands are the whole [rows, D] rollout arrays (read in place) and only the index batch is refilled."""

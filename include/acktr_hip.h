@@ -404,6 +404,19 @@ int acktr_gru_gates_fwd_f32(float* gi_rzn, const float* gh, const float* hm, con
                             float* hm_next, int N, int H, void* stream);
 int acktr_gru_gates_bwd_f32(const float* dout, const float* m_next, float* rzn_dgi, float* gh_dgh, const float* hm,
                             float* carry, int last, int N, int H, void* stream);
+/* One launch per time step for few rows (acktr_gru_step_supported: 1 <= N <= 64, H % 4 == 0), model.py:111-166 and its
+ * autograd backward -- the per-step product and the gate arithmetic of the three entries above in one kernel:
+ * step_fwd: gh[N,3H] = hm W_hh^T + b_hh (kept for the backward), then gates_fwd's arithmetic on gi_rzn / h_out / hm_next.
+ * step_bwd: step t of BPTT.  carry[N,H] holds dh*z of step t+1 on entry and of step t on return; dgh_next[N,3H] is step
+ *           t+1's d gh (as left by step_bwd), w_hh_t [H,3H] the TRANSPOSED W_hh (acktr_transpose_f32, once per pass):
+ *           dh = dout + (last ? 0 : (carry + dgh_next w_hh_t^T) * m_next[n]), then gates_bwd's arithmetic.
+ * transpose: dst[cols, rows] = src[rows, cols]^T. */
+int acktr_gru_step_supported(int N, int H);
+int acktr_gru_step_fwd_f32(float* gi_rzn, float* gh, const float* hm, const float* w_hh, const float* b_hh,
+                           const float* m_next, float* h_out, float* hm_next, int N, int H, void* stream);
+int acktr_gru_step_bwd_f32(const float* dout, const float* m_next, float* rzn_dgi, float* gh_dgh, const float* hm,
+                           const float* dgh_next, const float* w_hh_t, float* carry, int last, int N, int H, void* stream);
+int acktr_transpose_f32(const float* src, int rows, int cols, float* dst, void* stream);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,10 @@ _PROTOS = {
     'acktr_gru_mask_rows_f32': (c_i, [c_p, c_p, c_p, c_i, c_i, c_p]),
     'acktr_gru_gates_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_p]),
     'acktr_gru_gates_bwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_p]),
+    'acktr_gru_step_supported': (c_i, [c_i, c_i]),
+    'acktr_gru_step_fwd_f32': (c_i, [c_p] * 8 + [c_i, c_i, c_p]),
+    'acktr_gru_step_bwd_f32': (c_i, [c_p] * 8 + [c_i, c_i, c_i, c_p]),
+    'acktr_transpose_f32': (c_i, [c_p, c_i, c_i, c_p, c_p]),
 }
 
 

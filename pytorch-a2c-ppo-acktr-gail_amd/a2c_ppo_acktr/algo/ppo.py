@@ -267,18 +267,59 @@ class PPO():
             ac.bind_grads()
             self.optimizer.prepare()
             n_steps = 0
+            # Single process: the minibatch step (forward over T time steps, loss, BPTT, clip + Adam: ~300 launches at
+            # T = 128) is replayed from a hipGraph captured at the second update that sees the same storage and shapes;
+            # its operands are persistent buffers (row index, initial states, masks) refilled before every replay.
+            ne = N // self.num_mini_batch
+            key = ('rec', rollouts.obs.data_ptr(), rollouts.actions.data_ptr(), rollouts.returns.data_ptr(),
+                   rollouts.value_preds.data_ptr(), rollouts.action_log_probs.data_ptr(), T, N, ne,
+                   ac.flat_params.data_ptr(), self.clip_param, self.value_loss_coef, self.entropy_coef, self.max_grad_norm,
+                   self.use_clipped_value_loss)
+            graph_ok = (self.use_graph and ops.profiler is None and not self.dp.active and ne >= 1
+                        and self._seen_key == key)
+            if self._seen_key != key:
+                self._rgraph = None
+                self._rbuf = dict(idx=torch.zeros(T * ne, dtype=torch.int64, device=dev),
+                                  hxs=torch.zeros(ne, H, dtype=torch.float32, device=dev),
+                                  masks=torch.zeros(T * ne, 1, dtype=torch.float32, device=dev),
+                                  adv=torch.zeros(rows, dtype=torch.float32, device=dev),
+                                  loss_acc=torch.zeros(3, dtype=torch.float32, device=dev))
+            self._seen_key = key
+            if graph_ok:
+                rb = self._rbuf
+                rb['adv'].copy_(adv.view(rows))
+                rb['loss_acc'].zero_()
+                gb = dict(b, adv=rb['adv'], loss_acc=rb['loss_acc'], idx=rb['idx'], hxs=rb['hxs'], masks=rb['masks'],
+                          inv_batch=1.0 / (T * ne))
+                if self._rgraph is None:                    # capture (records only; executes nothing)
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        self._fwd_bwd(gb)
+                        self.optimizer.step(self.max_grad_norm, capturing=True)
+                        self.optimizer.step_count -= 1
+                    self._rgraph = g
             for e in range(self.ppo_epoch):
                 for envs in rollouts.recurrent_env_batches(self.num_mini_batch):
                     lo, hi = self.dp.bounds(envs.numel())
                     mine = envs[lo:hi].to(dev)
-                    b['idx'] = rollouts.recurrent_rows(mine)
-                    b['hxs'] = rollouts._gather(rollouts.recurrent_hidden_states[0].view(N, H), mine, N)
-                    b['masks'] = rollouts._gather(masks_flat, b['idx'], rows)
+                    idx = rollouts.recurrent_rows(mine)
+                    hxs = rollouts._gather(rollouts.recurrent_hidden_states[0].view(N, H), mine, N)
+                    masks = rollouts._gather(masks_flat, idx, rows)
+                    n_steps += 1
+                    if graph_ok and envs.numel() == ne:
+                        rb['idx'].copy_(idx)
+                        rb['hxs'].copy_(hxs)
+                        rb['masks'].copy_(masks)
+                        self._rgraph.replay()
+                        self.optimizer.step_count += 1
+                        continue
+                    b['idx'], b['hxs'], b['masks'] = idx, hxs, masks
                     b['inv_batch'] = 1.0 / (T * envs.numel())
                     self._fwd_bwd(b)
                     self.dp.all_reduce_sum_(ac.flat_grads)
                     self.optimizer.step(self.max_grad_norm)                            # ppo.py:82-84
-                    n_steps += 1
+            if graph_ok:
+                loss_acc.add_(rb['loss_acc'])
             self.dp.all_reduce_sum_(loss_acc)
             vl, al, en = (loss_acc / n_steps).tolist()
         return vl, al, en

@@ -135,10 +135,23 @@ def gru_forward(policy, a, x_seq, hxs, masks):
     out = torch.empty(B, H, dtype=f32, device=dev)
     _hip.check(L.acktr_gru_mask_rows_f32(_hip.dev_ptr(hxs), _hip.dev_ptr(masks), _hip.dev_ptr(hm), N, H, stream),
                'acktr_gru_mask_rows_f32')
+    # few rows per step (a minibatch of whole trajectories): product + gates in ONE launch per step; raw pointers, the
+    # loop body is one foreign call (as two launches behind torch slicing a step cost ~70 us of host time)
+    fused = GRU_STEP_FUSED and L.acktr_gru_step_supported(N, H) == 1
+    p_gi, p_gh, p_hm, p_out, p_m = gi.data_ptr(), gh.data_ptr(), hm.data_ptr(), out.data_ptr(), masks.data_ptr()
+    p_w, p_b = _hip.dev_ptr(w_hh), _hip.dev_ptr(b_hh)
+    vp = ctypes.c_void_p
     for t in range(T):
+        nxt = t + 1 < T
+        if fused:
+            rc = L.acktr_gru_step_fwd_f32(vp(p_gi + 12 * H * N * t), vp(p_gh + 12 * H * N * t), vp(p_hm + 4 * H * N * t), p_w, p_b,
+                                          vp(p_m + 4 * N * (t + 1)) if nxt else None, vp(p_out + 4 * H * N * t),
+                                          vp(p_hm + 4 * H * N * (t + 1)) if nxt else None, N, H, stream)
+            if rc:
+                _hip.check(rc, 'acktr_gru_step_fwd_f32')
+            continue
         s = slice(t * N, (t + 1) * N)
         ops.linear_fwd(hm[s], w_hh, b_hh, None, out=gh[s])
-        nxt = t + 1 < T
         rc = L.acktr_gru_gates_fwd_f32(_hip.dev_ptr(gi[s]), _hip.dev_ptr(gh[s]), _hip.dev_ptr(hm[s]),
                                        _hip.dev_ptr(masks[(t + 1) * N:(t + 2) * N]) if nxt else None,
                                        _hip.dev_ptr(out[s]),
@@ -163,9 +176,24 @@ def gru_backward(policy, a, dout, gflat, wgrad=True, dx_gate_src=None, dx_gate=N
     dout = dout.contiguous()
     carry = torch.empty(N, H, dtype=f32, device=dev)
     rzn, gh, hm, masks = a.gru_rzn, a.gru_gh, a.gru_hm, a.gru_masks
+    fused = GRU_STEP_FUSED and L.acktr_gru_step_supported(N, H) == 1
+    if fused:
+        w_t = torch.empty(H, 3 * H, dtype=f32, device=dev)           # rows of W_hh^T: what a hidden unit's carry sums over
+        _hip.check(L.acktr_transpose_f32(_hip.dev_ptr(w_hh), 3 * H, H, _hip.dev_ptr(w_t), stream), 'acktr_transpose_f32')
+        p_do, p_rzn, p_gh, p_hm, p_m = dout.data_ptr(), rzn.data_ptr(), gh.data_ptr(), hm.data_ptr(), masks.data_ptr()
+        p_wt, p_c = _hip.dev_ptr(w_t), _hip.dev_ptr(carry)
+        vp = ctypes.c_void_p
     for t in range(T - 1, -1, -1):
-        s = slice(t * N, (t + 1) * N)
         last = t == T - 1
+        if fused:
+            rc = L.acktr_gru_step_bwd_f32(vp(p_do + 4 * H * N * t), None if last else vp(p_m + 4 * N * (t + 1)),
+                                          vp(p_rzn + 12 * H * N * t), vp(p_gh + 12 * H * N * t), vp(p_hm + 4 * H * N * t),
+                                          None if last else vp(p_gh + 12 * H * N * (t + 1)), p_wt, p_c, 1 if last else 0, N, H,
+                                          stream)
+            if rc:
+                _hip.check(rc, 'acktr_gru_step_bwd_f32')
+            continue
+        s = slice(t * N, (t + 1) * N)
         rc = L.acktr_gru_gates_bwd_f32(_hip.dev_ptr(dout[s]),
                                        None if last else _hip.dev_ptr(masks[(t + 1) * N:(t + 2) * N]),
                                        _hip.dev_ptr(rzn[s]), _hip.dev_ptr(gh[s]), _hip.dev_ptr(hm[s]),
@@ -440,6 +468,7 @@ def head_step(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, o
 # ----------------------------------------------------------------------------------------------
 FUSED_MLP = os.environ.get('ACKTR_FUSED_MLP', '1') != '0'
 FOLD_PAD = os.environ.get('ACKTR_FOLD_PAD', '1') != '0'
+GRU_STEP_FUSED = os.environ.get('ACKTR_GRU_STEP_FUSED', '1') != '0'      # tuning / comparison switch
 
 
 def mlp_fused_ok(policy, B):

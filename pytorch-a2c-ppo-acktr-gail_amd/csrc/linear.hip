@@ -364,32 +364,70 @@ __global__ __launch_bounds__(256) void skinny_dgrad_kernel(const float* __restri
 }
 
 // per row slice: pw[slice][o][i] = sum_{b in slice} dy[b,o] x[b,i];  pb[slice][o] = sum_b dy[b,o]
+// A thread owns one 16-byte column quad; when the layer has fewer than 128 quads (the 64-wide MLP heads: 16) the other
+// threads of the workgroup take every nsub-th row of the slice and the partials meet in LDS in sub-slice order -- with one
+// row walker per quad the 65536-row minibatches of configs[4] kept 16 lanes of a workgroup busy for 241 us.
 __global__ __launch_bounds__(128) void skinny_wgrad_partial_kernel(const float* __restrict__ dy,
                                                                   const float* __restrict__ x, float* __restrict__ pw,
                                                                   float* __restrict__ pb, int B, int IN, int OUT,
                                                                   int rows_per_slice) {
-    const int c4 = (blockIdx.x * 128 + threadIdx.x) * 4;
+    __shared__ f32x4 red[128][SK_MAX_OUT];                             // 16 KB
+    __shared__ float redb[128][SK_MAX_OUT];
+    const int q = IN / 4;
+    const int nsub = q < 128 ? 128 / q : 1;                            // row walkers per quad (grid.x == 1 when q < 128)
+    const int sub = q < 128 ? threadIdx.x / q : 0;
+    const int cq = q < 128 ? threadIdx.x % q : blockIdx.x * 128 + threadIdx.x;
+    const int c4 = cq * 4;
+    const bool live = sub < nsub && c4 < IN;
     const int r0 = blockIdx.y * rows_per_slice;
     int r1 = r0 + rows_per_slice;
     if (r1 > B) r1 = B;
-    if (pb && blockIdx.x == 0 && threadIdx.x < OUT) {
-        float sb = 0.f;
-        for (int r = r0; r < r1; ++r) sb += dy[(long)r * OUT + threadIdx.x];
-        pb[(long)blockIdx.y * OUT + threadIdx.x] = sb;
-    }
-    if (c4 >= IN) return;
     f32x4 acc[SK_MAX_OUT];
+    float bs[SK_MAX_OUT];
 #pragma unroll
-    for (int o = 0; o < SK_MAX_OUT; ++o) acc[o] = zero4();
-    for (int r = r0; r < r1; ++r) {
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)r * IN + c4);
+    for (int o = 0; o < SK_MAX_OUT; ++o) { acc[o] = zero4(); bs[o] = 0.f; }
+    const bool bias_lane = pb && cq == 0 && blockIdx.x == 0;           // one lane per row walker also sums dy
+    if (live) {
+        for (int r = r0 + sub; r < r1; r += nsub) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (long)r * IN + c4);
+#pragma unroll
+            for (int o = 0; o < SK_MAX_OUT; ++o)
+                if (o < OUT) {
+                    const float d = dy[(long)r * OUT + o];
+                    acc[o] += d * xv;
+                    if (bias_lane) bs[o] += d;
+                }
+        }
+    }
+    if (nsub == 1) {                                                   // (uniform) one walker per quad: nothing to combine
+        if (live) {
+#pragma unroll
+            for (int o = 0; o < SK_MAX_OUT; ++o)
+                if (o < OUT) *reinterpret_cast<f32x4*>(pw + ((long)blockIdx.y * OUT + o) * IN + c4) = acc[o];
+            if (bias_lane)
+#pragma unroll
+                for (int o = 0; o < SK_MAX_OUT; ++o)
+                    if (o < OUT) pb[(long)blockIdx.y * OUT + o] = bs[o];
+        }
+        return;
+    }
+#pragma unroll
+    for (int o = 0; o < SK_MAX_OUT; ++o) { red[threadIdx.x][o] = acc[o]; redb[threadIdx.x][o] = bs[o]; }
+    __syncthreads();
+    if (threadIdx.x < q) {                                             // sub-slices added in order: deterministic
 #pragma unroll
         for (int o = 0; o < SK_MAX_OUT; ++o)
-            if (o < OUT) acc[o] += dy[(long)r * OUT + o] * xv;          // dy: wave-uniform address
+            if (o < OUT) {
+                f32x4 t = red[threadIdx.x][o];
+                for (int k = 1; k < nsub; ++k) t += red[k * q + threadIdx.x][o];
+                *reinterpret_cast<f32x4*>(pw + ((long)blockIdx.y * OUT + o) * IN + c4) = t;
+            }
     }
-#pragma unroll
-    for (int o = 0; o < SK_MAX_OUT; ++o)
-        if (o < OUT) *reinterpret_cast<f32x4*>(pw + ((long)blockIdx.y * OUT + o) * IN + c4) = acc[o];
+    if (pb && threadIdx.x < OUT) {
+        float t = 0.f;
+        for (int k = 0; k < nsub; ++k) t += redb[k * q][threadIdx.x];
+        pb[(long)blockIdx.y * OUT + threadIdx.x] = t;
+    }
 }
 // db[o] = sum over slices of pb[slice][o], fixed order: thread (g, o) sums slices g, g+32, ..., then the 32 groups in order
 __global__ __launch_bounds__(256) void skinny_bias_reduce_kernel(const float* __restrict__ pb, int nsl, int OUT,

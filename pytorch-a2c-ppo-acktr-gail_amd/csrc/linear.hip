@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void skinny_bias_reduce_kernel(const float* __
 static int skinny_slices(int B) {
     int n = B / 8;
     if (n < 1) n = 1;
-    if (n > 128) n = 128;
+    if (n > 128) n = B >= 16384 ? 512 : 128;          // (65536-row minibatches: 128 slices left 512 rows to every workgroup)
     return n;
 }
 

@@ -90,7 +90,9 @@ def test_conv_wgrad_large_batch_split_k_deterministic():
                                       # the stationary-accumulator weight gradient (128..512 tiles of 64x64, B >= 256):
                                       (1024, 1568, 512), (301, 1499, 501), (257, 700, 770),
                                       # the in-workgroup split-K forward (128..512 tiles of 64x32, IN % 4 == 0, IN >= 512):
-                                      (1000, 1564, 500), (513, 516, 300)])
+                                      (1000, 1564, 500), (513, 516, 300),
+                                      # skinny heads at configs[4]-class batch sizes (512 row slices, 8 row walkers per quad):
+                                      (20000, 64, 6), (16390, 64, 1)])
 @pytest.mark.parametrize('act', [None, 'relu', 'tanh'])
 def test_linear_fwd_bwd(B, IN, OUT, act):
     from a2c_ppo_acktr import ops

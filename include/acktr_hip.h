@@ -387,6 +387,11 @@ typedef struct acktr_mlp_step_args {
     float opt_max_norm;
     const float* opt_hyper_dev;
     int* opt_step_dev;
+    /* categorical != 0: the action head is distributions.py:59-73 Categorical(logits = h W_m^T + b_m) instead of
+     * DiagGaussian -- `actions_i64` [rows] replaces `actions`, `logstd` / `glogstd` are not used.  (Last, so that a
+     * zero-initialised tail keeps the DiagGaussian meaning of the fields above.) */
+    int categorical;
+    const int64_t* actions_i64;
 } acktr_mlp_step_args;
 int acktr_mlp_fused_step_supported(int B, int IN, int H, int A);
 int acktr_mlp_fused_step_f32(const acktr_mlp_step_args* args, void* stream);

@@ -44,7 +44,8 @@ class MlpStepArgs(ctypes.Structure):
                 [('clip', c_f), ('value_coef', c_f), ('entropy_coef', c_f), ('inv_batch', c_f),
                  ('use_clipped_value_loss', c_i), ('loss_acc', c_p)] +
                 [(n, c_p) for n in ('opt_params', 'opt_grads', 'opt_exp_avg', 'opt_exp_avg_sq')] +
-                [('opt_n', c_l), ('opt_max_norm', c_f), ('opt_hyper_dev', c_p), ('opt_step_dev', c_p)])
+                [('opt_n', c_l), ('opt_max_norm', c_f), ('opt_hyper_dev', c_p), ('opt_step_dev', c_p),
+                 ('categorical', c_i), ('actions_i64', c_p)])
 
 
 class ConvPackJob(ctypes.Structure):

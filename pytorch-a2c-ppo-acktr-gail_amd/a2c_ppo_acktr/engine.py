@@ -473,8 +473,8 @@ GRU_STEP_FUSED = os.environ.get('ACKTR_GRU_STEP_FUSED', '1') != '0'      # tunin
 
 def mlp_fused_ok(policy, B):
     """The fused single-workgroup step covers the reference's MuJoCo shape: non-recurrent MLPBase(hidden 64) with a
-    DiagGaussian head, up to 64 rows.  Anything else runs layer by layer."""
-    if not FUSED_MLP or is_cnn(policy) or policy.is_recurrent or ops.profiler is not None or policy.dist.kind != 1:
+    DiagGaussian (or Categorical) head, up to 64 rows.  Anything else runs layer by layer."""
+    if not FUSED_MLP or is_cnn(policy) or policy.is_recurrent or ops.profiler is not None or policy.dist.kind not in (0, 1):
         return False
     b = policy.base
     if hasattr(b.actor[0], 'add_bias'):            # KFAC's split_bias surgery: ACKTR needs the per-layer activations
@@ -496,7 +496,8 @@ def mlp_fused_step(policy, obs, gather_idx, B, algo, actions, loss_acc, inv_batc
         raise RuntimeError('policy inputs must be contiguous float32 tensors on the MI355X device')
     a = _hip.MlpStepArgs()
     p = lambda t, dt=f32, name='mlp step operand': (None if t is None else _hip.dev_ptr(t, dt, name).value)
-    ls = logstd_param(policy)
+    cat = policy.dist.kind == 0
+    ls = None if cat else logstd_param(policy)
     for k, (w, b) in (('c0', L['c0']), ('c2', L['c2']), ('a0', L['a0']), ('a2', L['a2'])):
         setattr(a, 'w' + k, p(w.detach())); setattr(a, 'b' + k, p(b.detach()))
         setattr(a, 'gw' + k, p(policy.grad_view(w, gflat))); setattr(a, 'gb' + k, p(policy.grad_view(b, gflat)))
@@ -504,12 +505,17 @@ def mlp_fused_step(policy, obs, gather_idx, B, algo, actions, loss_acc, inv_batc
     a.gwv, a.gbv = p(policy.grad_view(L['critic'][0], gflat)), p(policy.grad_view(L['critic'][1], gflat))
     a.wm, a.bm = p(L['mean'][0].detach()), p(L['mean'][1].detach())
     a.gwm, a.gbm = p(policy.grad_view(L['mean'][0], gflat)), p(policy.grad_view(L['mean'][1], gflat))
-    a.logstd, a.glogstd = p(ls.detach()), p(policy.grad_view(ls, gflat))
+    if not cat:
+        a.logstd, a.glogstd = p(ls.detach()), p(policy.grad_view(ls, gflat))
     a.obs = p(obs)
     a.gather_idx = p(gather_idx, torch.int64, 'gather_idx')
     H, IN = L['a0'][0].shape
     a.B, a.IN, a.H, a.A, a.algo = int(B), int(IN), int(H), int(policy.dist.num_outputs), int(algo)
-    a.actions = p(actions, f32, 'actions')
+    if cat:
+        a.categorical = 1
+        a.actions_i64 = p(actions, torch.int64, 'actions')
+    else:
+        a.actions = p(actions, f32, 'actions')
     a.old_logp, a.old_values, a.returns, a.adv = p(old_logp), p(old_values), p(returns), p(adv)
     a.clip, a.value_coef, a.entropy_coef, a.inv_batch = clip, value_coef, entropy_coef, inv_batch
     a.use_clipped_value_loss = 1 if use_clipped_value_loss else 0

@@ -62,7 +62,7 @@ __host__ __device__ inline MfLds mf_layout(int IN, int A) {
     return L;
 }
 
-template <int ALGO>
+template <int ALGO, bool CAT>
 __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_step_args a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, tw = tid >> 8, t256 = tid & 255;
@@ -149,27 +149,59 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_st
         for (int j = 0; j < MF_MAX_A; ++j) { dls[j] = 0.f; dm[j] = 0.f; }
         if (r < B) {
             const long src = a.gather_idx ? (long)a.gather_idx[r] : (long)r;
-            const float* act = a.actions + src * A;
-            float actv[MF_MAX_A];
-#pragma unroll
-            for (int j = 0; j < MF_MAX_A; ++j) actv[j] = j < A ? act[j] : 0.f;
-            const DistEval d = gaussian_eval(mean, a.logstd, actv, A);
             const float o_logp = a.old_logp ? a.old_logp[src] : 0.f;
             const float o_val = a.old_values ? a.old_values[src] : 0.f;
             const float ret = a.returns ? a.returns[src] : 0.f;
             const float advn = a.adv ? a.adv[src] : 0.f;
-            const LossTerms t = algo_terms<ALGO>(d.logp, v, o_logp, o_val, ret, advn, a.clip, a.use_clipped_value_loss);
-            vl = t.vl; al = t.al; en = d.ent;
-            const float dlogp = t.dlogp * a.inv_batch;
-            dv = a.value_coef * t.dv * a.inv_batch;
-            const float dent = -a.entropy_coef * a.inv_batch;
+            if constexpr (CAT) {
+                // distributions.py:59-73 Categorical on the logits `mean[]` (the arithmetic of head_fused.hip's phase B)
+                const long act64 = a.actions_i64[src];
+                const int act_l = (act64 >= 0 && act64 < A) ? (int)act64 : -1;
+                float mx = mean[0];
 #pragma unroll
-            for (int j = 0; j < MF_MAX_A; ++j) {
-                if (j < A) {
-                    const float sd = expf(a.logstd[j]);
-                    const float var = sd * sd, dj = actv[j] - mean[j];
-                    dm[j] = dlogp * dj / var;
-                    dls[j] = dlogp * (dj * dj / var - 1.f) + dent;
+                for (int j = 1; j < MF_MAX_A; ++j) if (j < A) mx = fmaxf(mx, mean[j]);
+                float se = 0.f;
+#pragma unroll
+                for (int j = 0; j < MF_MAX_A; ++j) if (j < A) se += expf(mean[j] - mx);
+                const float lse = mx + logf(se);
+                float ent = 0.f, za = 0.f;
+#pragma unroll
+                for (int j = 0; j < MF_MAX_A; ++j) if (j < A) {
+                    const float lp = fmaxf(mean[j] - lse, -3.402823466e+38f);
+                    ent -= lp * expf(lp);
+                    if (j == act_l) za = mean[j];
+                }
+                const float logp = act_l >= 0 ? za - lse : 0.f;
+                const LossTerms t = algo_terms<ALGO>(logp, v, o_logp, o_val, ret, advn, a.clip, a.use_clipped_value_loss);
+                vl = t.vl; al = t.al; en = ent;
+                const float dlogp = t.dlogp * a.inv_batch;
+                dv = a.value_coef * t.dv * a.inv_batch;
+                const float dent = -a.entropy_coef * a.inv_batch;
+#pragma unroll
+                for (int j = 0; j < MF_MAX_A; ++j)
+                    if (j < A) {
+                        const float lp = mean[j] - lse, pr = expf(lp);
+                        dm[j] = dlogp * ((j == act_l ? 1.f : 0.f) - pr) - dent * pr * (lp + ent);
+                    }
+            } else {
+                const float* act = a.actions + src * A;
+                float actv[MF_MAX_A];
+#pragma unroll
+                for (int j = 0; j < MF_MAX_A; ++j) actv[j] = j < A ? act[j] : 0.f;
+                const DistEval d = gaussian_eval(mean, a.logstd, actv, A);
+                const LossTerms t = algo_terms<ALGO>(d.logp, v, o_logp, o_val, ret, advn, a.clip, a.use_clipped_value_loss);
+                vl = t.vl; al = t.al; en = d.ent;
+                const float dlogp = t.dlogp * a.inv_batch;
+                dv = a.value_coef * t.dv * a.inv_batch;
+                const float dent = -a.entropy_coef * a.inv_batch;
+#pragma unroll
+                for (int j = 0; j < MF_MAX_A; ++j) {
+                    if (j < A) {
+                        const float sd = expf(a.logstd[j]);
+                        const float var = sd * sd, dj = actv[j] - mean[j];
+                        dm[j] = dlogp * dj / var;
+                        dls[j] = dlogp * (dj * dj / var - 1.f) + dent;
+                    }
                 }
             }
         }
@@ -190,7 +222,7 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_fused_step_kernel(acktr_mlp_st
         for (int j = 0; j < MF_MAX_A; ++j) {
             if (j < A) {                                         // uniform
                 const float s1 = wave_sum(dls[j]), s2 = wave_sum(dm[j]);
-                if (tid == 0) { a.glogstd[j] = s1; a.gbm[j] = s2; }
+                if (tid == 0) { if (!CAT) a.glogstd[j] = s1; a.gbm[j] = s2; }
             }
         }
     }
@@ -350,11 +382,12 @@ extern "C" int acktr_mlp_fused_step_f32(const acktr_mlp_step_args* args, void* s
               "mlp_fused_step: unsupported shape B=%d IN=%d H=%d A=%d (B <= %d, H == %d, IN <= %d, A <= %d)", a.B, a.IN,
               a.H, a.A, MF_ROWS, MF_H, MF_MAX_IN, MF_MAX_A);
     ACKTR_ARG(a.algo == 0 || a.algo == 1, "mlp_fused_step: algo must be 0 (PPO) or 1 (A2C)");
+    const bool cat = a.categorical != 0;
     ACKTR_ARG(a.wc0 && a.bc0 && a.wc2 && a.bc2 && a.wa0 && a.ba0 && a.wa2 && a.ba2 && a.wv && a.bv && a.wm && a.bm &&
-                  a.logstd, "mlp_fused_step: null parameter pointer");
+                  (cat || a.logstd), "mlp_fused_step: null parameter pointer");
     ACKTR_ARG(a.gwc0 && a.gbc0 && a.gwc2 && a.gbc2 && a.gwa0 && a.gba0 && a.gwa2 && a.gba2 && a.gwv && a.gbv && a.gwm &&
-                  a.gbm && a.glogstd, "mlp_fused_step: null gradient pointer");
-    ACKTR_ARG(a.obs && a.actions, "mlp_fused_step: null observations / actions");
+                  a.gbm && (cat || a.glogstd), "mlp_fused_step: null gradient pointer");
+    ACKTR_ARG(a.obs && (cat ? a.actions_i64 != nullptr : a.actions != nullptr), "mlp_fused_step: null observations / actions");
     ACKTR_ARG(a.algo != 0 || (a.old_logp && a.old_values && a.returns && a.adv), "mlp_fused_step: PPO needs rollout arrays");
     ACKTR_ARG(a.algo != 1 || a.returns, "mlp_fused_step: A2C needs returns");
     ACKTR_ARG(!a.opt_params || (a.opt_grads && a.opt_exp_avg && a.opt_exp_avg_sq && a.opt_hyper_dev && a.opt_step_dev && a.opt_n > 0),
@@ -365,24 +398,21 @@ extern "C" int acktr_mlp_fused_step_f32(const acktr_mlp_step_args* args, void* s
     const MfLds L = mf_layout(a.IN, a.A);
     const int smem = L.total * (int)sizeof(float);
     ACKTR_ARG(smem <= 160 * 1024, "mlp_fused_step: LDS budget exceeded (%d bytes)", smem);
-    static bool attr_set[2] = {false, false};
-    auto set_attr = [&](const void* fn, int which) -> int {
-        if (attr_set[which]) return 0;
-        hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) { set_error("mlp_fused_step: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
-        attr_set[which] = true;
+    static bool attr_set[4] = {false, false, false, false};
+    auto launch = [&](auto kern, int which) -> int {
+        if (!attr_set[which]) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               160 * 1024);
+            if (e != hipSuccess) { set_error("mlp_fused_step: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+            attr_set[which] = true;
+        }
+        hipLaunchKernelGGL(kern, dim3(1), dim3(MF_THREADS), smem, (hipStream_t)stream, a);
         return 0;
     };
-    hipStream_t s = (hipStream_t)stream;
-    if (a.algo == 0) {
-        int rc = set_attr(reinterpret_cast<const void*>(mlp_fused_step_kernel<0>), 0);
-        if (rc) return rc;
-        hipLaunchKernelGGL(mlp_fused_step_kernel<0>, dim3(1), dim3(MF_THREADS), smem, s, a);
-    } else {
-        int rc = set_attr(reinterpret_cast<const void*>(mlp_fused_step_kernel<1>), 1);
-        if (rc) return rc;
-        hipLaunchKernelGGL(mlp_fused_step_kernel<1>, dim3(1), dim3(MF_THREADS), smem, s, a);
-    }
+    int rc;
+    if (a.algo == 0) rc = cat ? launch(mlp_fused_step_kernel<0, true>, 2) : launch(mlp_fused_step_kernel<0, false>, 0);
+    else rc = cat ? launch(mlp_fused_step_kernel<1, true>, 3) : launch(mlp_fused_step_kernel<1, false>, 1);
+    if (rc) return rc;
     ACKTR_LAUNCH_CHECK();
     return 0;
 }

@@ -659,26 +659,24 @@ extern "C" int acktr_kfac_precondition_f32(const float* grad, const float* qt_g,
     return gemm_rowmajor(tmp1, IN, 1, qt_a, 1, IN, e4, OUT, IN, IN, 1, s);
 }
 
-// All layers at once: stage s of every layer's four-product chain is one grouped launch (gemm_group.hpp).  Layers whose
-// shapes allow 16-byte operand loads (OUT % 4 == IN % 4 == 0, aligned pointers) form one group per stage, the rest (heads
-// with 1 / 6 outputs, the 1-column bias modules) a second one on the scalar-load instantiation.
+// All layers at once: stage s of every layer's four-product chain is one grouped launch (gemm_group.hpp); 16-byte or
+// scalar operand loads are chosen per operand and per layer inside the kernel.
 namespace acktr {
-template <bool VEC>
-static int precondition_group(const acktr_precond_job* jb, const int* sel, int n, float damping, hipStream_t s) {
-    GroupDense<VEC, true> kc_a, kc_b;
-    GroupDense<VEC, false> rc_a, rc_b;
+static int precondition_group(const acktr_precond_job* jb, int n, float damping, hipStream_t s) {
+    GroupDense<true> kc_a, kc_b;
+    GroupDense<false> rc_a, rc_b;
     GroupEpi e;
     int maxOUT = 0, maxIN = 0;
     for (int i = 0; i < n; ++i) {
-        if (jb[sel[i]].OUT > maxOUT) maxOUT = jb[sel[i]].OUT;
-        if (jb[sel[i]].IN > maxIN) maxIN = jb[sel[i]].IN;
+        if (jb[i].OUT > maxOUT) maxOUT = jb[i].OUT;
+        if (jb[i].IN > maxIN) maxIN = jb[i].IN;
     }
     int rc;
     // T1 = Qg^T G : A(m,k) = qt_g[m*OUT + k], B(n,k) = grad[k*IN + n]
     for (int i = 0; i < n; ++i) {
-        const acktr_precond_job& J = jb[sel[i]];
-        kc_a.j[i] = GroupOpJob{J.qt_g, J.OUT, J.OUT, (long)J.OUT};
-        rc_b.j[i] = GroupOpJob{J.grad, J.IN, J.OUT, (long)J.IN};
+        const acktr_precond_job& J = jb[i];
+        kc_a.j[i] = group_op(J.qt_g, J.OUT, J.OUT, J.OUT, true);
+        rc_b.j[i] = group_op(J.grad, J.IN, J.OUT, J.IN, false);
         e.j[i] = GroupEpiJob{J.tmp1, J.OUT, J.IN, (long)J.IN, J.d_g, J.d_a};
     }
     e.div_add = damping; e.use_div = 0;
@@ -686,9 +684,9 @@ static int precondition_group(const acktr_precond_job* jb, const int* sel, int n
     if (rc) return rc;
     // T2 = (T1 Qa) / (dg da^T + lambda) : A(m,k) = tmp1[m*IN + k], B(n,k) = qt_a[n*IN + k]
     for (int i = 0; i < n; ++i) {
-        const acktr_precond_job& J = jb[sel[i]];
-        kc_a.j[i] = GroupOpJob{J.tmp1, J.OUT, J.IN, (long)J.IN};
-        kc_b.j[i] = GroupOpJob{J.qt_a, J.IN, J.IN, (long)J.IN};
+        const acktr_precond_job& J = jb[i];
+        kc_a.j[i] = group_op(J.tmp1, J.OUT, J.IN, J.IN, true);
+        kc_b.j[i] = group_op(J.qt_a, J.IN, J.IN, J.IN, true);
         e.j[i].c = J.tmp2;
     }
     e.use_div = 1;
@@ -696,9 +694,9 @@ static int precondition_group(const acktr_precond_job* jb, const int* sel, int n
     if (rc) return rc;
     // T3 = Qg T2 : A(m,k) = qt_g[k*OUT + m], B(n,k) = tmp2[k*IN + n]
     for (int i = 0; i < n; ++i) {
-        const acktr_precond_job& J = jb[sel[i]];
-        rc_a.j[i] = GroupOpJob{J.qt_g, J.OUT, J.OUT, (long)J.OUT};
-        rc_b.j[i] = GroupOpJob{J.tmp2, J.IN, J.OUT, (long)J.IN};
+        const acktr_precond_job& J = jb[i];
+        rc_a.j[i] = group_op(J.qt_g, J.OUT, J.OUT, J.OUT, false);
+        rc_b.j[i] = group_op(J.tmp2, J.IN, J.OUT, J.IN, false);
         e.j[i].c = J.tmp1;
     }
     e.use_div = 0;
@@ -706,9 +704,9 @@ static int precondition_group(const acktr_precond_job* jb, const int* sel, int n
     if (rc) return rc;
     // V = T3 Qa^T : A(m,k) = tmp1[m*IN + k], B(n,k) = qt_a[k*IN + n]
     for (int i = 0; i < n; ++i) {
-        const acktr_precond_job& J = jb[sel[i]];
-        kc_a.j[i] = GroupOpJob{J.tmp1, J.OUT, J.IN, (long)J.IN};
-        rc_b.j[i] = GroupOpJob{J.qt_a, J.IN, J.IN, (long)J.IN};
+        const acktr_precond_job& J = jb[i];
+        kc_a.j[i] = group_op(J.tmp1, J.OUT, J.IN, J.IN, true);
+        rc_b.j[i] = group_op(J.qt_a, J.IN, J.IN, J.IN, false);
         e.j[i].c = J.v_out;
     }
     return launch_gemm_z<64, 64, 2, 2>(kc_a, rc_b, e, maxOUT, maxIN, maxIN, n, s);
@@ -718,25 +716,17 @@ static int precondition_group(const acktr_precond_job* jb, const int* sel, int n
 extern "C" int acktr_kfac_precondition_batched_f32(const acktr_precond_job* jobs, int count, float damping, void* stream) {
     ACKTR_ARG(jobs && count > 0, "kfac_precondition_batched: no jobs");
     hipStream_t s = (hipStream_t)stream;
-    int vec[GROUP_MAX], sca[GROUP_MAX], nv = 0, nsc = 0;
-    auto flush = [&](bool v) -> int {
-        int rc = 0;
-        if (v && nv) { rc = precondition_group<true>(jobs, vec, nv, damping, s); nv = 0; }
-        if (!v && nsc) { rc = precondition_group<false>(jobs, sca, nsc, damping, s); nsc = 0; }
-        return rc;
-    };
     for (int i = 0; i < count; ++i) {
         const acktr_precond_job& J = jobs[i];
         ACKTR_ARG(J.grad && J.qt_g && J.d_g && J.qt_a && J.d_a && J.tmp1 && J.tmp2 && J.v_out && J.OUT > 0 && J.IN > 0,
                   "kfac_precondition_batched: job %d has a null pointer or a bad size", i);
-        const uintptr_t al = (uintptr_t)J.grad | (uintptr_t)J.qt_g | (uintptr_t)J.qt_a | (uintptr_t)J.tmp1 | (uintptr_t)J.tmp2;
-        const bool v = (J.OUT % 4 == 0) && (J.IN % 4 == 0) && (al % 16 == 0);
-        if (v) { vec[nv++] = i; if (nv == GROUP_MAX) { int rc = flush(true); if (rc) return rc; } }
-        else { sca[nsc++] = i; if (nsc == GROUP_MAX) { int rc = flush(false); if (rc) return rc; } }
     }
-    int rc = flush(true);
-    if (rc) return rc;
-    return flush(false);
+    for (int i0 = 0; i0 < count; i0 += GROUP_MAX) {
+        const int n = count - i0 < GROUP_MAX ? count - i0 : GROUP_MAX;
+        const int rc = precondition_group(jobs + i0, n, damping, s);
+        if (rc) return rc;
+    }
+    return 0;
 }
 
 extern "C" int acktr_kfac_kl_clip_f32(const float* v, const float* g, long n, float lr, float kl_clip,

@@ -298,12 +298,15 @@ int acktr_kfac_precondition_f32(const float* grad, const float* qt_g, const floa
                                 const float* d_a, int OUT, int IN, float damping, float* tmp1, float* tmp2,
                                 float* v_out, void* stream);
 /* reference kfac.py:216-227 for ALL layers of a step at once: the same four products as acktr_kfac_precondition_f32, with
- * stage s of every layer in one grouped launch (4 launches, or 8 when some layers rule out 16-byte loads, instead of 4 per
- * layer).  Each job needs its OWN tmp1 / tmp2 of OUT*IN floats (the layers run concurrently); v_out may not alias them. */
+ * stage s of every layer in one grouped launch (4 launches per 16 layers instead of 4 per layer).  Each job needs its OWN tmp1 / tmp2 of OUT*IN floats (the layers run concurrently); v_out may not alias them. */
 typedef struct acktr_precond_job {
     const float* grad; const float* qt_g; const float* d_g; const float* qt_a; const float* d_a;
     float* tmp1; float* tmp2; float* v_out;
     int OUT; int IN;
+    /* optional (both or neither, for every job of a call): the eigenvector matrices themselves, q_g [OUT,OUT] = qt_g^T and
+     * q_a [IN,IN] = qt_a^T (acktr_transpose_f32 after each eigendecomposition).  With them every operand of the four
+     * stages is contiguous along its output index and the stages run on stationary accumulators (kfac.hip). */
+    const float* q_g; const float* q_a;
 } acktr_precond_job;
 int acktr_kfac_precondition_batched_f32(const acktr_precond_job* jobs, int count, float damping, void* stream);
 

@@ -62,7 +62,7 @@ class JacobiJob(ctypes.Structure):
 class PrecondJob(ctypes.Structure):
     """struct acktr_precond_job (include/acktr_hip.h)"""
     _fields_ = [('grad', c_p), ('qt_g', c_p), ('d_g', c_p), ('qt_a', c_p), ('d_a', c_p), ('tmp1', c_p), ('tmp2', c_p),
-                ('v_out', c_p), ('OUT', c_i), ('IN', c_i)]
+                ('v_out', c_p), ('OUT', c_i), ('IN', c_i), ('q_g', c_p), ('q_a', c_p)]
 
 
 class EigJob(ctypes.Structure):

@@ -154,6 +154,7 @@ class KFACOptimizer(optim.Optimizer):
         self.aa_sample, self.gg_sample = z(oa), z(og)
         self.aa_run, self.gg_run = z(oa), z(og)
         self.qt_a, self.qt_g = z(oa), z(og)
+        self.q_a, self.q_g = z(oa), z(og)               # the eigenvector matrices themselves (transposes of the qt slots)
         self.d_a_flat, self.d_g_flat = z(da), z(dg)
         for m in self._mods:
             mod = m.module
@@ -434,7 +435,8 @@ class KFACOptimizer(optim.Optimizer):
                     ctypes.c_void_p(self.d_g_flat.data_ptr() + 4 * m.dg_off), ctypes.c_void_p(self.qt_a.data_ptr() + 4 * m.oa),
                     ctypes.c_void_p(self.d_a_flat.data_ptr() + 4 * m.da_off),
                     _hip.dev_ptr(pol.grad_view(m.param, self._pj_tmp[0])), _hip.dev_ptr(pol.grad_view(m.param, self._pj_tmp[1])),
-                    _hip.dev_ptr(pol.grad_view(m.param, self.v_flat)), m.ng, m.na)
+                    _hip.dev_ptr(pol.grad_view(m.param, self.v_flat)), m.ng, m.na,
+                    ctypes.c_void_p(self.q_g.data_ptr() + 4 * m.og), ctypes.c_void_p(self.q_a.data_ptr() + 4 * m.oa))
             self._pj_arr, self._pj_key = arr, key
         return self._pj_arr
 
@@ -452,6 +454,15 @@ class KFACOptimizer(optim.Optimizer):
             la = self.damping + self.weight_decay
             if self.steps % self.Tf == 0:
                 self._eigendecompose()
+                # Q next to Q^T: with both, every operand of the four preconditioner products is contiguous along its output
+                # index (stationary-accumulator stages, kfac.hip); 24 small transposes every Tf steps
+                for m in self._mods:
+                    for qt, q, off, n in ((self.qt_a, self.q_a, m.oa, m.na), (self.qt_g, self.q_g, m.og, m.ng)):
+                        if n > 1:
+                            _hip.check(L.acktr_transpose_f32(ctypes.c_void_p(qt.data_ptr() + 4 * off), n, n,
+                                                             ctypes.c_void_p(q.data_ptr() + 4 * off), stream), 'acktr_transpose_f32')
+                        else:
+                            q[off:off + 1].copy_(qt[off:off + 1])
             # kfac.py:216-227 for every layer: stage s of all layers in one grouped launch (acktr_kfac_precondition_batched_f32)
             jobs = self._precond_jobs(pol, gflat)
             with ops._Timed('kfac_precondition_all', sum(4.0 * m.ng * m.na * (m.ng + m.na) for m in self._mods)):

@@ -713,6 +713,159 @@ static int precondition_group(const acktr_precond_job* jb, int n, float damping,
 }
 }  // namespace acktr
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same four stages on stationary accumulators (cf. fc_wgrad_sa_kernel, linear.hip).  With BOTH the eigenvector matrix
+// Q and its transpose at hand (acktr_precond_job.q_g / q_a), and with stages 1 and 3 storing their result transposed,
+// every operand of every stage is contiguous along its OUTPUT index:
+//   T1^T[n,m] = sum_k Qg[k,m] G[k,n]        T2[m,n] = (sum_k T1^T[k,m] Qa[k,n]) / (dg[m] da[n] + lambda)
+//   T3^T[n,m] = sum_k Qg^T[k,m] T2[k,n]     V[m,n]  = sum_k T3^T[k,m] Qa^T[k,n]
+// so MFMA operands are coalesced loads straight into registers; one workgroup per 64x64 tile of a layer's result, its
+// eight waves split K and meet in LDS in wave order (deterministic).  All layers of a stage share one launch (a workgroup
+// finds its layer by the tile prefix in the kernel arguments).  The tile GEMM ran the 512 x 1568 layer's 200 tiles at one
+// 4-wave workgroup per CU over a K of 1568: 28-43 TFLOP/s.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace acktr {
+constexpr int PS_WAVES = 8, PS_PITCH = 65, PS_LDS_BYTES = PS_WAVES * 64 * PS_PITCH * 4;
+struct PsJob {
+    const float* a; const float* b; float* c; const float* div_m; const float* div_n;
+    int M, N, K, lda, ldb, ldc, tile0, tiles_n, v2, transposed;
+};
+struct PsJobs { PsJob j[GROUP_MAX]; int count; float div_add; };
+
+__global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) {
+    typedef float ps2 __attribute__((ext_vector_type(2)));
+    typedef ps2 ps2u __attribute__((aligned(8)));
+    extern __shared__ __attribute__((aligned(16))) float ps_smem[];           // [wave][blk 4][reg 16][PS_PITCH]
+    int z = 0;
+    while (z + 1 < jobs.count && (int)blockIdx.x >= jobs.j[z + 1].tile0) ++z;  // (uniform)
+    const PsJob& J = jobs.j[z];
+    // (plain tile order: dealing a layer's column tiles to the XCDs as fc_wgrad_sa_kernel does measured SLOWER here --
+    //  45 / 100 us against 30 / 77 us for the 0.8 / 2.5 GFLOP stages of the 512 x 1568 layer)
+    const int t = blockIdx.x - J.tile0;
+    const int m0 = (t / J.tiles_n) * 64, n0 = (t % J.tiles_n) * 64;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
+    const int M = J.M, N = J.N, K = J.K, lda = J.lda, ldb = J.ldb;
+    const bool V2 = J.v2 != 0;
+    const int per = ((K + 2 * PS_WAVES - 1) / (2 * PS_WAVES)) * 2;
+    const int k0 = wave * per, k1 = min(K, k0 + per);
+    const int mc0 = V2 ? m0 + 2 * li : m0 + li, mc1 = V2 ? mc0 + 1 : mc0 + 32;
+    const int nc0 = V2 ? n0 + 2 * li : n0 + li, nc1 = V2 ? nc0 + 1 : nc0 + 32;
+    const bool mok0 = mc0 < M, mok1 = mc1 < M, nok0 = nc0 < N, nok1 = nc1 < N;
+    const float* ap = J.a + mc0;
+    const float* bp = J.b + nc0;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
+    constexpr int U = 8;
+    float av[2][U][2], bv[2][U][2];
+    auto load_blk = [&](int buf, int k) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kk = k + 2 * u + kh;
+            const bool ok = kk < k1;
+            const long ra = (long)(ok ? kk : 0) * lda, rb = (long)(ok ? kk : 0) * ldb;
+            if (V2) {                                                          // (uniform; pairs are whole: M, N, m0, n0 even)
+                const ps2 a2 = (ok && mok0) ? *reinterpret_cast<const ps2u*>(ap + ra) : ps2{0.f, 0.f};
+                const ps2 b2 = (ok && nok0) ? *reinterpret_cast<const ps2u*>(bp + rb) : ps2{0.f, 0.f};
+                av[buf][u][0] = a2[0]; av[buf][u][1] = a2[1];
+                bv[buf][u][0] = b2[0]; bv[buf][u][1] = b2[1];
+            } else {
+                av[buf][u][0] = (ok && mok0) ? ap[ra] : 0.f;
+                av[buf][u][1] = (ok && mok1) ? ap[ra + 32] : 0.f;
+                bv[buf][u][0] = (ok && nok0) ? bp[rb] : 0.f;
+                bv[buf][u][1] = (ok && nok1) ? bp[rb + 32] : 0.f;
+            }
+        }
+    };
+    auto mul_blk = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[buf][u][a], bv[buf][u][b], acc[a][b], 0, 0, 0);
+    };
+    if (k0 < k1) {
+        load_blk(0, k0);
+        for (int k = k0; k < k1; k += 4 * U) {
+            load_blk(1, k + 2 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_blk(0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_blk(0, k + 4 * U);
+            __builtin_amdgcn_sched_barrier(0);
+            mul_blk(1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    float* mine = ps_smem + (long)wave * (64 * PS_PITCH);
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) mine[((a * 2 + b) * 16 + v) * PS_PITCH + lane] = acc[a][b][v];
+    __syncthreads();
+    // 4096 results over 512 threads, consecutive threads along the destination's contiguous index
+    const bool tr = J.transposed != 0;
+    for (int e = threadIdx.x; e < 4096; e += 64 * PS_WAVES) {
+        const int ml = tr ? (e & 63) : (e >> 6), nl = tr ? (e >> 6) : (e & 63);
+        const int a = V2 ? (ml & 1) : (ml >> 5), i = V2 ? (ml >> 1) : (ml & 31);
+        const int b = V2 ? (nl & 1) : (nl >> 5), jn = V2 ? (nl >> 1) : (nl & 31);
+        const int v = (i & 3) | ((i >> 3) << 2), l = (((i >> 2) & 1) << 5) | jn;
+        const int off = ((a * 2 + b) * 16 + v) * PS_PITCH + l;
+        float sum = 0.f;
+#pragma unroll
+        for (int w = 0; w < PS_WAVES; ++w) sum += ps_smem[w * (64 * PS_PITCH) + off];
+        const int m = m0 + ml, n = n0 + nl;
+        if (m < M && n < N) {
+            if (J.div_m) sum = sum / (J.div_m[m] * J.div_n[n] + jobs.div_add);
+            if (tr) J.c[(long)n * J.ldc + m] = sum; else J.c[(long)m * J.ldc + n] = sum;
+        }
+    }
+}
+
+static int precondition_sa_group(const acktr_precond_job* jb, int n, float damping, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(precond_sa_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS_BYTES);
+        if (e != hipSuccess) { set_error("precondition_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    for (int stage = 0; stage < 4; ++stage) {
+        PsJobs jobs;
+        jobs.count = n; jobs.div_add = damping;
+        int tiles = 0;
+        for (int i = 0; i < n; ++i) {
+            const acktr_precond_job& J = jb[i];
+            PsJob& P = jobs.j[i];
+            P.M = J.OUT; P.N = J.IN; P.div_m = nullptr; P.div_n = nullptr;
+            switch (stage) {
+                case 0: P.a = J.q_g; P.lda = J.OUT; P.b = J.grad; P.ldb = J.IN; P.K = J.OUT; P.c = J.tmp1; P.transposed = 1; break;
+                case 1: P.a = J.tmp1; P.lda = J.OUT; P.b = J.q_a; P.ldb = J.IN; P.K = J.IN; P.c = J.tmp2; P.transposed = 0;
+                        P.div_m = J.d_g; P.div_n = J.d_a; break;
+                case 2: P.a = J.qt_g; P.lda = J.OUT; P.b = J.tmp2; P.ldb = J.IN; P.K = J.OUT; P.c = J.tmp1; P.transposed = 1; break;
+                default: P.a = J.tmp1; P.lda = J.OUT; P.b = J.qt_a; P.ldb = J.IN; P.K = J.IN; P.c = J.v_out; P.transposed = 0; break;
+            }
+            P.ldc = P.transposed ? J.OUT : J.IN;
+            P.v2 = (J.OUT % 2 == 0 && J.IN % 2 == 0 && ((((uintptr_t)P.a) | ((uintptr_t)P.b)) & 7) == 0) ? 1 : 0;
+            P.tiles_n = cdiv(J.IN, 64);
+            P.tile0 = tiles;
+            tiles += cdiv(J.OUT, 64) * P.tiles_n;
+        }
+        hipLaunchKernelGGL(precond_sa_kernel, dim3(tiles), dim3(64 * PS_WAVES), PS_LDS_BYTES, s, jobs);
+        ACKTR_LAUNCH_CHECK();
+    }
+    return 0;
+}
+}  // namespace acktr
+
 extern "C" int acktr_kfac_precondition_batched_f32(const acktr_precond_job* jobs, int count, float damping, void* stream) {
     ACKTR_ARG(jobs && count > 0, "kfac_precondition_batched: no jobs");
     hipStream_t s = (hipStream_t)stream;
@@ -721,9 +874,12 @@ extern "C" int acktr_kfac_precondition_batched_f32(const acktr_precond_job* jobs
         ACKTR_ARG(J.grad && J.qt_g && J.d_g && J.qt_a && J.d_a && J.tmp1 && J.tmp2 && J.v_out && J.OUT > 0 && J.IN > 0,
                   "kfac_precondition_batched: job %d has a null pointer or a bad size", i);
     }
+    static const bool tile_only = getenv("ACKTR_PRECOND_TILE") != nullptr;      // tuning / comparison switch
+    bool have_q = !tile_only;
+    for (int i = 0; i < count; ++i) have_q = have_q && jobs[i].q_g && jobs[i].q_a;
     for (int i0 = 0; i0 < count; i0 += GROUP_MAX) {
         const int n = count - i0 < GROUP_MAX ? count - i0 : GROUP_MAX;
-        const int rc = precondition_group(jobs + i0, n, damping, s);
+        const int rc = have_q ? precondition_sa_group(jobs + i0, n, damping, s) : precondition_group(jobs + i0, n, damping, s);
         if (rc) return rc;
     }
     return 0;

@@ -245,12 +245,14 @@ def test_patch_mean_vs_torch(H, K, S, C, B):
         assert rel(out.cpu().numpy(), ref.numpy()) < 2e-6
 
 
-def test_precondition_batched_vs_torch():
+@pytest.mark.parametrize('with_q', [False, True])
+def test_precondition_batched_vs_torch(with_q):
     """acktr_kfac_precondition_batched_f32: every layer shape class of the two policies in ONE call (16-byte and scalar
-    load groups, 1-column bias modules, 1- and 6-row heads, more jobs than one group holds) against torch fp64."""
+    loads, 1-column bias modules, 1- and 6-row heads, more jobs than one group holds) against torch fp64 -- on the grouped
+    tile GEMM (jobs without q_g / q_a) and on the stationary-accumulator stages (with them)."""
     from a2c_ppo_acktr import _hip
     shapes = [(512, 1568), (64, 512), (32, 576), (32, 256), (1, 512), (6, 512), (512, 1), (64, 1), (32, 1), (6, 1), (1, 1),
-              (64, 64), (64, 11), (3, 64), (64, 17)] + [(8, 12)] * 6
+              (64, 64), (64, 11), (3, 64), (64, 17), (130, 70)] + [(8, 12)] * 6
     g = torch.Generator().manual_seed(5)
     keep, refs, outs = [], [], []
     jobs = (_hip.PrecondJob * len(shapes))()
@@ -263,9 +265,11 @@ def test_precondition_batched_vs_torch():
         dev = lambda x: x.float().contiguous().cuda()
         ts = [dev(G), dev(Qg.t()), dev(dg), dev(Qa.t()), dev(da), torch.empty(OUT * IN, device='cuda'),
               torch.empty(OUT * IN, device='cuda'), torch.empty(OUT, IN, device='cuda')]
-        keep.append(ts)
+        qs = [dev(Qg), dev(Qa)]
+        keep.append((ts, qs))
         outs.append(ts[7])
-        jobs[i] = _hip.PrecondJob(*[_hip.dev_ptr(x) for x in ts], OUT, IN)
+        jobs[i] = _hip.PrecondJob(*[_hip.dev_ptr(x) for x in ts], OUT, IN,
+                                  *([_hip.dev_ptr(x) for x in qs] if with_q else [None, None]))
     _hip.check(_hip.lib().acktr_kfac_precondition_batched_f32(jobs, len(shapes), 0.01, _hip.cur_stream()), 'precondition_batched')
     for (OUT, IN), v, ref in zip(shapes, outs, refs):
         assert rel(v.cpu().numpy(), ref.numpy()) < 5e-5, (OUT, IN)

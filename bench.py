@@ -325,7 +325,10 @@ def side_metrics(device):
                        # every update draws torch.randperm over all T*N rollout rows on the CPU first (reference
                        # storage.py:119-123 through gail.py:60, same RNG stream): a fixed host cost per update
                        cpu_randperm_ms_per_update=round(rp_ms, 3),
-                       us_per_discriminator_step_net_of_randperm=round(max(res[64][0] - rp_ms, 0.0) * 1e3 / res[64][1], 1))
+                       # marginal cost of a minibatch step: both updates pay ONE permutation, they differ by 24 steps
+                       # (subtracting a separately timed randperm instead swung by +-100 us with the host's mood)
+                       us_per_discriminator_step_net_of_randperm=round(
+                           (res[64][0] - res[4][0]) * 1e3 / max(res[64][1] - res[4][1], 1), 1))
     return out
 
 

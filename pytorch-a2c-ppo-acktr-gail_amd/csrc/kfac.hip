@@ -760,7 +760,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) 
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
-    constexpr int U = 8;
+    constexpr int U = 2;                                                       // (cf. fc_wgrad_sa_kernel: fine interleave beats deep prefetch)
     float av[2][U][2], bv[2][U][2];
     auto load_blk = [&](int buf, int k) {
 #pragma unroll

@@ -628,8 +628,12 @@ constexpr int FW_WAVES = 8, FW_LDS_BYTES = FW_WAVES * 64 * 64 * 4;
 // V2 (OUT and IN even, 8-byte aligned operands): a lane loads TWO adjacent outputs with one 8-byte load and the two 32-wide
 // MFMA blocks of a tile side are interleaved (block a = outputs m0 + 2i + a): half the load instructions per MFMA -- with
 // dword loads the kernel ran at the same ~48 TFLOP/s for 1024 and for 8192 batch rows, paced by load issue, not by the MFMAs.
-template <bool V2>
-__global__ __launch_bounds__(64 * FW_WAVES) void fc_wgrad_sa_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+// U = k pairs per register block: 2 measured best (26.0 us for the policy's FC layer; 1: 27.7, 3: 26.4, 4: 27.0, 8: 31.0;
+// 16 waves with U = 4 / 2: 33.2 / 30.1) -- the loads alone and the MFMAs alone each take the same ~13.7 us of this kernel's
+// loop (64x64 tiles: 16 flop per loaded byte, and a CU draws ~16 B/clk from L2), so what counts is how finely the two
+// interleave, not how far ahead the loads run.
+template <bool V2, int W = FW_WAVES, int U = 2>
+__global__ __launch_bounds__(64 * W) void fc_wgrad_sa_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                       float* __restrict__ dw, float* __restrict__ db, int B,
                                                                       int IN, int OUT, int tiles_n) {
     typedef float fw2 __attribute__((ext_vector_type(2)));
@@ -642,7 +646,7 @@ __global__ __launch_bounds__(64 * FW_WAVES) void fc_wgrad_sa_kernel(const float*
     if (nt >= tiles_n) return;                                                  // (uniform: before any barrier)
     const int m0 = (local / slots) * 64, n0 = nt * 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
-    const int per = ((B + 2 * FW_WAVES - 1) / (2 * FW_WAVES)) * 2;              // rows per wave, even
+    const int per = ((B + 2 * W - 1) / (2 * W)) * 2;                            // rows per wave, even
     const int k0 = wave * per, k1 = min(B, k0 + per);
     // column of block a held by this lane: V2: m0 + 2 li + a, else m0 + 32 a + li
     const int mc0 = V2 ? m0 + 2 * li : m0 + li, mc1 = V2 ? mc0 + 1 : mc0 + 32;
@@ -658,7 +662,6 @@ __global__ __launch_bounds__(64 * FW_WAVES) void fc_wgrad_sa_kernel(const float*
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[a][b][v] = 0.f;
     float bs0 = 0.f, bs1 = 0.f;
-    constexpr int U = 8;                                                        // k pairs per register block
     float av[2][U][2], xv[2][U][2];
     auto load_blk = [&](int buf, int k) {
 #pragma unroll
@@ -704,21 +707,34 @@ __global__ __launch_bounds__(64 * FW_WAVES) void fc_wgrad_sa_kernel(const float*
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    float* mine = fw_smem + (long)wave * 4096;
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) mine[((a * 2 + b) * 16 + v) * 64 + lane] = acc[a][b][v];
-    __shared__ float bsum[FW_WAVES][2][64];
+    float* mine = fw_smem + (long)(wave & (FW_WAVES - 1)) * 4096;
+    __shared__ float bsum[W][2][64];
     bsum[wave][0][lane] = bs0;
     bsum[wave][1][lane] = bs1;
+    if (wave < FW_WAVES) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) mine[((a * 2 + b) * 16 + v) * 64 + lane] = acc[a][b][v];
+    }
     __syncthreads();
+    if constexpr (W > FW_WAVES) {                                               // waves 8..15 add into the slot of wave - 8
+        if (wave >= FW_WAVES) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) mine[((a * 2 + b) * 16 + v) * 64 + lane] += acc[a][b][v];
+        }
+        __syncthreads();
+    }
     // the eight partial tiles added in wave order; accumulator (a, b, v, l) is row i = 4 (l/32) + (v&3) + 8 (v>>2), column
     // j = l%32 of block (a, b)
     if constexpr (V2) {
-        for (int e = threadIdx.x; e < 2048; e += 64 * FW_WAVES) {              // (a, v, l): both b of a lane, one 8-byte store
+        for (int e = threadIdx.x; e < 2048; e += 64 * W) {                     // (a, v, l): both b of a lane, one 8-byte store
             const int a = e >> 10, v = (e >> 6) & 15, l = e & 63;
             fw2 sum = fw2{0.f, 0.f};
 #pragma unroll
@@ -730,7 +746,7 @@ __global__ __launch_bounds__(64 * FW_WAVES) void fc_wgrad_sa_kernel(const float*
             if (m < OUT && n < IN) *reinterpret_cast<fw2u*>(dw + (long)m * IN + n) = sum;
         }
     } else {
-        for (int e = threadIdx.x; e < 4096; e += 64 * FW_WAVES) {
+        for (int e = threadIdx.x; e < 4096; e += 64 * W) {
             float sum = 0.f;
 #pragma unroll
             for (int w = 0; w < FW_WAVES; ++w) sum += fw_smem[w * 4096 + e];
@@ -743,7 +759,7 @@ __global__ __launch_bounds__(64 * FW_WAVES) void fc_wgrad_sa_kernel(const float*
         const int a = threadIdx.x >> 5, l = threadIdx.x & 31;
         float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < FW_WAVES; ++w) sum += bsum[w][a][l] + bsum[w][a][l + 32];
+        for (int w = 0; w < W; ++w) sum += bsum[w][a][l] + bsum[w][a][l + 32];
         const int m = V2 ? m0 + 2 * l + a : m0 + 32 * a + l;
         if (m < OUT) db[m] = sum;
     }
@@ -754,17 +770,17 @@ static bool fc_wgrad_sa_ok(int B, int IN, int OUT) {
     const long tiles = (long)cdiv(OUT, 64) * cdiv(IN, 64);
     return !off && B >= 256 && B <= 4096 && OUT > SK_MAX_OUT && tiles >= 128 && tiles <= 2L * sw_num_cus();   // (B = 8192: the tile GEMM's long K loop is 0.3 % ahead)
 }
-template <bool V2>
+template <bool V2, int W = FW_WAVES, int U = 2>
 static int fc_wgrad_sa_t(const float* dy, const float* x, float* dw, float* db, int B, int IN, int OUT, hipStream_t s) {
     static bool attr_set = false;                                               // per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_wgrad_sa_kernel<V2>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fc_wgrad_sa_kernel<V2, W, U>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, FW_LDS_BYTES);
         if (e != hipSuccess) { set_error("fc_wgrad_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
     const int tn = cdiv(IN, 64);
-    hipLaunchKernelGGL((fc_wgrad_sa_kernel<V2>), dim3(cdiv(OUT, 64) * cdiv(tn, 8) * 8), dim3(64 * FW_WAVES), FW_LDS_BYTES, s, dy,
+    hipLaunchKernelGGL((fc_wgrad_sa_kernel<V2, W, U>), dim3(cdiv(OUT, 64) * cdiv(tn, 8) * 8), dim3(64 * W), FW_LDS_BYTES, s, dy,
                        x, dw, db, B, IN, OUT, tn);
     ACKTR_LAUNCH_CHECK();
     return 0;

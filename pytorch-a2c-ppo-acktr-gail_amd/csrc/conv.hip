@@ -117,7 +117,7 @@ static int conv3_wgrad_sa(const float* x, const float* dy, float* dw, float* db,
     const long wk = (long)SA_OC * KC, slab = wk + SA_OC;
     const int per = cdiv(B, sw_num_cus()), ns = cdiv(B, per);
     if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
-    hipLaunchKernelGGL((conv3_wgrad_sa_kernel<C>), dim3(ns), dim3(C * SA_KK), 0, s, x, dy, ws, slab, B, per, scale);
+    hipLaunchKernelGGL((conv3_wgrad_sa_kernel<C>), dim3(ns), dim3(64 * SA3_WAVES), 0, s, x, dy, ws, slab, B, per, scale);
     ACKTR_LAUNCH_CHECK();
     if (db == dw + wk) return launch_slab_reduce(dw, ws, ns, wk + SA_OC, slab, 1.f, 0, s);
     int rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);

@@ -12,11 +12,12 @@
 // The tile-GEMM wgrad of this layer ran at 36 TFLOP/s: its K loop per workgroup was 12 tiles long between a pipeline
 // fill and a 16 KB slab write.
 #pragma once
+#include <type_traits>
 #include "gemm_core.hpp"
 
 namespace acktr {
 
-constexpr int SA_OC = 32, SA_KK = 9, SA_H = 9, SA_OH = 7, SA_SP = 49, SA_HW = 81;
+constexpr int SA_OC = 32, SA_KK = 9, SA_H = 9, SA_OH = 7, SA_SP = 49, SA_HW = 81, SA3_WAVES = 10;
 
 // One row of one image: the three 16-byte operand loads of a lane.  Lanes of the upper k half (h = 1) would need
 // positions 4..7 of the row, of which 7 does not exist -- and whose window may lie one float past the tensor.  They
@@ -40,6 +41,7 @@ __device__ __forceinline__ f32x4 sa_shift(const f32x4& v, int kh, float last) {
     r[0] = kh ? v[1] : v[0]; r[1] = kh ? v[2] : v[1]; r[2] = kh ? v[3] : v[2]; r[3] = kh ? last : v[3];
     return r;
 }
+template <bool FULL>
 __device__ __forceinline__ void sa_consume(const SaRow& r, int kh, f32x16 (&acc)[2], float& bsum) {
     const f32x4 a = sa_shift(r.a, kh, 0.f);                   // position 7 of the row does not exist: A is zero there
     const f32x4 b0 = sa_shift(r.b0, kh, r.b0[3]), b1 = sa_shift(r.b1, kh, r.b1[3]);
@@ -47,23 +49,27 @@ __device__ __forceinline__ void sa_consume(const SaRow& r, int kh, f32x16 (&acc)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b0[j], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[1], 0, 0, 0);
+        if constexpr (FULL) acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b1[j], acc[1], 0, 0, 0);
     }
 }
 
-// grid = number of slabs; block = (C*9/64) waves.  slab layout: [OC * C*9 | OC]
+// grid = number of slabs; slab layout: [OC * C*9 | OC].  The C*9/32 = 18 tap tiles go to TEN waves: eight with two tiles
+// and two with one (waves 8 and 9, which land on different SIMDs) -- nine two-tile waves put three on one SIMD and two on
+// the others (672 MFMAs per image run against 448), ten put 2.5 on two of them (560).
 template <int C>
-__global__ __launch_bounds__(C * SA_KK) void conv3_wgrad_sa_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                                  float* __restrict__ slabs, long slab_stride, int B,
-                                                                  int imgs_per_wg, float scale) {
-    static_assert((C * SA_KK) % 64 == 0, "whole waves of 64 taps");
+__global__ __launch_bounds__(64 * SA3_WAVES) void conv3_wgrad_sa_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                       float* __restrict__ slabs, long slab_stride, int B,
+                                                                       int imgs_per_wg, float scale) {
+    static_assert(C * SA_KK == 32 * (2 * (SA3_WAVES - 2) + 2), "eight two-tile waves + two one-tile waves");
     constexpr int KC = C * SA_KK;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, kh = lane >> 5;
+    const bool full = wave < SA3_WAVES - 2;
+    const int tile0 = full ? 2 * wave : wave + (SA3_WAVES - 2);                // first 32-tap tile of this wave
     int tapoff[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int n = 64 * wave + 32 * t + li;
+        const int n = 32 * (tile0 + (full ? t : 0)) + li;                     // (a one-tile wave loads its tile twice)
         const int c = n / SA_KK, r9 = n % SA_KK;
         tapoff[t] = 4 * (c * SA_HW + (r9 / 3) * SA_H + (r9 % 3) + 3 * kh);   // bytes
     }
@@ -91,21 +97,25 @@ __global__ __launch_bounds__(C * SA_KK) void conv3_wgrad_sa_kernel(const float* 
                                                                // loop head are merged to the worse of the two
         }
     }
-    for (int b = b0; b < b1; ++b) {
-        const int bn = b + 1 < b1 ? b + 1 : b1 - 1;
-        const int xs = bn * C * SA_HW * 4, dys = bn * SA_OC * SA_SP * 4;
+    auto run = [&](auto full_c) {
+        for (int b = b0; b < b1; ++b) {
+            const int bn = b + 1 < b1 ? b + 1 : b1 - 1;
+            const int xs = bn * C * SA_HW * 4, dys = bn * SA_OC * SA_SP * 4;
 #pragma unroll
-        for (int oy = 0; oy < SA_OH; ++oy) {
-            sa_consume(ring[oy], kh, acc, bsum);
-            sa_issue(ring[oy], xr, dyr, xs, dys, aoff, tapoff, oy);
-            __builtin_amdgcn_sched_barrier(0);                 // keep the refill right behind its row: the scheduler would
+            for (int oy = 0; oy < SA_OH; ++oy) {
+                sa_consume<decltype(full_c)::value>(ring[oy], kh, acc, bsum);
+                sa_issue(ring[oy], xr, dyr, xs, dys, aoff, tapoff, oy);
+                __builtin_amdgcn_sched_barrier(0);             // keep the refill right behind its row: the scheduler would
                                                                // otherwise collect all 21 loads at the end of the image
+            }
         }
-    }
+    };
+    if (full) run(std::true_type{}); else run(std::false_type{});
     float* slab = slabs + (long)blockIdx.x * slab_stride;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        const int tap = 64 * wave + 32 * t + li;
+        if (t == 1 && !full) break;
+        const int tap = 32 * (tile0 + t) + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int oc = (r & 3) + 8 * (r >> 2) + 4 * kh;

@@ -254,7 +254,7 @@ int sw_num_cus() {
 using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, 8, HM_KX, 512, false>;
 using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, 8, HM_KY, 512>;
 using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, 12, HM_CH, 512>;
-using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 12, HM_CH, 768>;    // padded 7x7 dY, flipped 3x3 kernel
+using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 8, HM_CH, 768>;     // padded 7x7 dY, flipped 3x3 kernel (stages of 8: room for the prefetched gate in 168 registers)
 using SwD2 = SwGeom<2, 2, 1, 11, 11, 64, 4, 2, 8, HM_CH, 512>;     // padded 9x9 dY, four 2x2 phase kernels stacked along M
 
 static long sw_fwd_image_bytes(int geom, int C, int OC) {
@@ -326,18 +326,30 @@ extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, c
         if (geom == GEOM_8S4) {
             if (!prepacked) rc = launch_sw_pack<SwF1>(w, img, OC, 0, 0, 0, s);
             if (rc) return rc;
-            SwFwdEpi<SwF1::SP> epi{y, bias, OC, in_scale, relu};
+            if (bias) {
+                SwFwdEpi<SwF1::SP, true> epi{y, bias, OC, in_scale, relu};
+                return launch_conv_sw<SwF1>(x, gather_idx, img, epi, B * SwF1::SP, s);
+            }
+            SwFwdEpi<SwF1::SP, false> epi{y, nullptr, OC, in_scale, relu};
             return launch_conv_sw<SwF1>(x, gather_idx, img, epi, B * SwF1::SP, s);
         }
         if (geom == GEOM_4S2) {
             if (!prepacked) rc = launch_sw_pack<SwF2>(w, img, OC, 0, 0, 0, s);
             if (rc) return rc;
-            SwFwdEpi<SwF2::SP> epi{y, bias, OC, in_scale, relu};
+            if (bias) {
+                SwFwdEpi<SwF2::SP, true> epi{y, bias, OC, in_scale, relu};
+                return launch_conv_sw<SwF2>(x, gather_idx, img, epi, B * SwF2::SP, s);
+            }
+            SwFwdEpi<SwF2::SP, false> epi{y, nullptr, OC, in_scale, relu};
             return launch_conv_sw<SwF2>(x, gather_idx, img, epi, B * SwF2::SP, s);
         }
         if (!prepacked) rc = launch_sw_pack<SwF3>(w, img, OC, 0, 0, 0, s);
         if (rc) return rc;
-        SwFwdEpi<SwF3::SP> epi{y, bias, OC, in_scale, relu};
+        if (bias) {
+            SwFwdEpi<SwF3::SP, true> epi{y, bias, OC, in_scale, relu};
+            return launch_conv_sw<SwF3>(x, gather_idx, img, epi, B * SwF3::SP, s);
+        }
+        SwFwdEpi<SwF3::SP, false> epi{y, nullptr, OC, in_scale, relu};
         return launch_conv_sw<SwF3>(x, gather_idx, img, epi, B * SwF3::SP, s);
     }
     if (geom == GEOM_8S4) {
@@ -461,13 +473,21 @@ extern "C" int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const 
             ACKTR_ARG(!dx_padded, "conv2d_dgrad: dx_padded is only produced by the 3x3 stride-1 stationary path");
             if (!prepacked) rc = launch_sw_pack<SwD2>(w, img, 4 * C, 1, C, 2, s);
             if (rc) return rc;
-            SwPhase2Epi<10, 10, 20, 20> epi{dx, x_act};
+            if (x_act) {
+                SwPhase2Epi<10, 10, 20, 20, true> epi{dx, x_act};
+                return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s);
+            }
+            SwPhase2Epi<10, 10, 20, 20, false> epi{dx, nullptr};
             return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s);
         }
         if (!prepacked) rc = launch_sw_pack<SwD3>(w, img, C, 1, C, 1, s);
         if (rc) return rc;
         const int pw = W + 2 * pad;
-        SwGateEpi<81> epi{dx, x_act, C, dx_padded, W, pw, (H + 2 * pad) * pw, pad * pw + pad};
+        if (x_act) {
+            SwGateEpi<81, true> epi{dx, x_act, C, dx_padded, W, pw, (H + 2 * pad) * pw, pad * pw + pad};
+            return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s);
+        }
+        SwGateEpi<81, false> epi{dx, nullptr, C, dx_padded, W, pw, (H + 2 * pad) * pw, pad * pw + pad};
         return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s);
     }
     ACKTR_ARG(!prepadded && !dx_padded, "conv2d_dgrad: padded operands need the stationary-weight path (this shape runs the tile GEMM)");

@@ -156,31 +156,36 @@ __global__ __launch_bounds__(256) void sw_pad_kernel(const float* __restrict__ d
 // ---------------------------------------------------------------------------------------------------
 // epilogues: lane = position r (valid or not), half h, acc[a][reg] -> row m = 32a + (reg&3) + 8(reg>>2) + 4h
 // ---------------------------------------------------------------------------------------------------
-template <int SP>
+template <int SP, bool BIASED>
 struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
     float* y; const float* bias; int M; float scale; int relu;
+    template <int TM> struct Pre { float bv[BIASED ? TM : 1][16]; };
     template <int TM>
-    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM]) const {
+    __device__ __forceinline__ void prefetch(int, bool, int h, int mg, Pre<TM>& p) const {   // (see SwGateEpi)
+        if constexpr (BIASED) {
+            const int m0 = 32 * TM * mg;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    p.bv[a][g] = bias[m < M ? m : M - 1];
+                }
+        }
+    }
+    template <int TM>
+    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM], const Pre<TM>& p) const {
         const long off = (long)(r / SP) * M * SP + (r % SP);
         const bool full = (M % 32 == 0);                  // wave-uniform: no per-row bound checks
         const int m0 = 32 * TM * mg;
         if (m0 >= M) return;
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            float bv[16];
-#pragma unroll
-            for (int g = 0; g < 16; ++g) bv[g] = 0.f;
-            if (bias) {                                   // wave-uniform; all bias loads first, then the stores
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
-                    const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
-                    bv[g] = bias[m < M ? m : M - 1];
-                }
-            }
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
-                float v = acc[a][g] * scale + bv[g];
+                float v = acc[a][g] * scale;
+                if constexpr (BIASED) v += p.bv[a][g];
                 if (relu) v = v > 0.f ? v : 0.f;
                 if (valid && (full || m < M)) y[off + (long)m * SP] = v;
             }
@@ -188,14 +193,34 @@ struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
     }
 };
 
-template <int SP>
+// Epilogues with a gate read it in prefetch(), which the kernel calls one stage of MFMAs before the tile is finished
+// (issued in store() the 16 gate loads of a lane were latency nothing overlapped: 8 us of the conv3 dgrad's 52).  The
+// loads are unconditional (indices clamped) and GATED is a compile-time switch: behind a run-time branch the compiler
+// can no longer count the loads in flight.
+template <int SP, bool GATED>
 struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
     float* dx; const float* xact; int M;
     // optional second copy of dX in the zero-padded plane layout the NEXT layer's dgrad reads ([b][m][psz] planes of
     // rows pw long, interior origin at poff0, the layer's own rows ow long): saves that layer's padding pass
     float* dxp; int ow, pw, psz, poff0;
+    template <int TM> struct Pre { float gv[GATED ? TM : 1][16]; };
     template <int TM>
-    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM]) const {
+    __device__ __forceinline__ void prefetch(int r, bool valid, int h, int mg, Pre<TM>& p) const {
+        if constexpr (GATED) {
+            const int rr = valid ? r : 0;
+            const long off = (long)(rr / SP) * M * SP + (rr % SP);
+            const int m0 = 32 * TM * mg;
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
+                    p.gv[a][g] = xact[off + (long)(m < M ? m : M - 1) * SP];
+                }
+        }
+    }
+    template <int TM>
+    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM], const Pre<TM>& p) const {
         const int m0 = 32 * TM * mg;
         if (!valid || m0 >= M) return;
         const long off = (long)(r / SP) * M * SP + (r % SP);
@@ -203,16 +228,11 @@ struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
         const bool full = (M % 32 == 0);
 #pragma unroll
         for (int a = 0; a < TM; ++a) {
-            float gv[16];
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
                 const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
-                gv[g] = xact ? xact[off + (long)(m < M ? m : M - 1) * SP] : 1.f;
-            }
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
-                const float v = gv[g] > 0.f ? acc[a][g] : 0.f;
+                float v = acc[a][g];
+                if constexpr (GATED) v = p.gv[a][g] > 0.f ? v : 0.f;
                 if (full || m < M) {
                     dx[off + (long)m * SP] = v;
                     if (dxp) dxp[offp + (long)m * psz] = v;
@@ -224,30 +244,43 @@ struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
 
 // stride-2 dgrad, CX == 32: M block = phase (py, px), one work item = the two px phases of row phase py = mg;
 // position r = (b, jy, jx) of the JH x JW phase grid; dX[b, cx, 2jy+py, 2jx + {0,1}] leaves as one 8-byte store
-template <int JH, int JW, int IH, int IW>
+template <int JH, int JW, int IH, int IW, bool GATED>
 struct SwPhase2Epi {
     float* dx; const float* xact;
+    static constexpr int JP = JH * JW;
+    __device__ __forceinline__ static long offset(int r, int mg) {
+        const int b = r / JP, j = r % JP;
+        const int jy = j / JW, jx = j % JW;
+        return (long)b * 32 * (IH * IW) + (2 * jy + mg) * IW + 2 * jx;
+    }
+    template <int TM> struct Pre { f32x2 gt[GATED ? 16 : 1]; };
     template <int TM>
-    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM]) const {
+    __device__ __forceinline__ void prefetch(int r, bool valid, int h, int mg, Pre<TM>& p) const {
+        if constexpr (GATED) {
+            const long off = offset(valid ? r : 0, mg);
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int cx = (g & 3) + 8 * (g >> 2) + 4 * h;
+                p.gt[g] = *reinterpret_cast<const f32x2*>(xact + off + (long)cx * (IH * IW));
+            }
+        }
+    }
+    template <int TM>
+    __device__ __forceinline__ void store(int r, bool valid, int h, int mg, const f32x16 (&acc)[TM], const Pre<TM>& p) const {
         static_assert(TM == 2, "one work item = the two horizontal phases of one row phase");
         static_assert(IH % 2 == 0 && IW % 2 == 0 && 2 * JH == IH && 2 * JW == IW, "even phase grid");
         if (!valid) return;
-        constexpr int JP = JH * JW;
-        const int b = r / JP, j = r % JP;
-        const int jy = j / JW, jx = j % JW;
-        const long off = (long)b * 32 * (IH * IW) + (2 * jy + mg) * IW + 2 * jx;
-        f32x2 gt[16];
-#pragma unroll
-        for (int g = 0; g < 16; ++g) {
-            const int cx = (g & 3) + 8 * (g >> 2) + 4 * h;
-            gt[g] = xact ? *reinterpret_cast<const f32x2*>(xact + off + (long)cx * (IH * IW)) : f32x2{1.f, 1.f};
-        }
+        const long off = offset(r, mg);
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
             const int cx = (g & 3) + 8 * (g >> 2) + 4 * h;
             f32x2 v;
-            v[0] = gt[g][0] > 0.f ? acc[0][g] : 0.f;
-            v[1] = gt[g][1] > 0.f ? acc[1][g] : 0.f;
+            v[0] = acc[0][g];
+            v[1] = acc[1][g];
+            if constexpr (GATED) {
+                v[0] = p.gt[g][0] > 0.f ? v[0] : 0.f;
+                v[1] = p.gt[g][1] > 0.f ? v[1] : 0.f;
+            }
             *reinterpret_cast<f32x2*>(dx + off + (long)cx * (IH * IW)) = v;
         }
     }
@@ -356,8 +389,13 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
         const int mg_next = has_next ? next_item % MG : mg;
         if (has_next) base_next = lane_base(next_item / MG, r_next, valid_next);
 
+        typename Epi::template Pre<TMW> pre;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
+            if (s == NS - 1) {                 // the epilogue's own reads fly over the last stage of MFMAs
+                epi.template prefetch<TMW>(r, valid, h, mg, pre);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             // the activations of stage s+1 (or of the next item's stage 0: it flies over the epilogue) are requested
             // a whole stage of MFMAs before they are needed
             // (unconditional: behind a branch the compiler can no longer count the loads in flight and drains them;
@@ -377,7 +415,7 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        epi.template store<TMW>(r, valid, h, mg, acc);
+        epi.template store<TMW>(r, valid, h, mg, acc, pre);
         if (!has_next) break;
         item = next_item; base = base_next; r = r_next; valid = valid_next; mg = mg_next; ++kround;
     }

@@ -190,6 +190,17 @@ int acktr_head_step_supported(int B, int H, int A, int dist);
 long acktr_head_step_workspace_bytes(int B, int H, int A);
 int acktr_head_step_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh, float* dfeat,
                         float* dwh, float* dbh, int H, void* stream);
+/* The same step with its second launch (the fixed-order sum of the workgroup slabs into dwh / dbh / loss_acc) left
+ * PENDING: `*pending` (host memory) describes it, and acktr_clip_adam_dev_head_f32 runs it as extra workgroups of its
+ * gradient-norm launch -- one dependent launch fewer per minibatch step (algo/ppo.py:57-84 as one sequence).  dfeat is
+ * complete on return of the stream work; dwh / dbh / loss_acc are NOT until the pending finalize has run.  No
+ * counterpart in the reference. */
+typedef struct acktr_head_fin {
+    const float* slabs; int nb; long stride; int n4; int nw; int OUT;
+    float* gw; float* gb; float* loss_acc; float inv_batch;
+} acktr_head_fin;
+int acktr_head_step_deferred_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh,
+                                 float* dfeat, float* dwh, float* dbh, int H, acktr_head_fin* pending, void* stream);
 
 /* dist.log_probs(action) and dist.entropy() per sample -- model.py:74-77 (entropy.mean() is taken by the host). */
 int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions, int B, int A,
@@ -222,6 +233,11 @@ int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_
  * (bias corrections evaluated in double on the device).  No counterpart in the reference (host loop there). */
 int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_grad_norm,
                             const float* hyper_dev, int* step_dev, void* workspace, void* stream);
+/* acktr_clip_adam_dev_f32 with a pending head finalize (acktr_head_step_deferred_f32) carried in the norm launch; dwh and
+ * dbh of `pending` must lie inside `grads`; max_grad_norm > 0 required. */
+int acktr_clip_adam_dev_head_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                 float max_grad_norm, const float* hyper_dev, int* step_dev,
+                                 const acktr_head_fin* pending, void* workspace, void* stream);
 /* clip_grad_norm_ + optim.RMSprop.step -- algo/a2c_acktr.py:74-78 (torch/optim/rmsprop.py:316-339). */
 int acktr_clip_rmsprop_f32(float* params, float* grads, float* square_avg, long n, float max_grad_norm, float lr,
                            float alpha, float eps, float* total_norm_out, void* workspace, void* stream);

@@ -59,6 +59,12 @@ class JacobiJob(ctypes.Structure):
     _fields_ = [('a', c_p), ('d', c_p), ('qt', c_p), ('n', c_i)]
 
 
+class HeadFin(ctypes.Structure):
+    """struct acktr_head_fin (include/acktr_hip.h): a head step's pending finalize"""
+    _fields_ = [('slabs', c_p), ('nb', c_i), ('stride', c_l), ('n4', c_i), ('nw', c_i), ('OUT', c_i),
+                ('gw', c_p), ('gb', c_p), ('loss_acc', c_p), ('inv_batch', c_f)]
+
+
 class PrecondJob(ctypes.Structure):
     """struct acktr_precond_job (include/acktr_hip.h)"""
     _fields_ = [('grad', c_p), ('qt_g', c_p), ('d_g', c_p), ('qt_a', c_p), ('d_a', c_p), ('tmp1', c_p), ('tmp2', c_p),
@@ -102,12 +108,15 @@ _PROTOS = {
     'acktr_head_step_supported': (c_i, [c_i, c_i, c_i, c_i]),
     'acktr_head_step_workspace_bytes': (c_l, [c_i, c_i, c_i]),
     'acktr_head_step_f32': (c_i, [ctypes.POINTER(LossArgs), c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
+    'acktr_head_step_deferred_f32': (c_i, [ctypes.POINTER(LossArgs), c_p, c_p, c_p, c_p, c_p, c_p, c_i,
+                                           ctypes.POINTER(HeadFin), c_p]),
     'acktr_dist_fwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
     'acktr_dist_act_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
     'acktr_dist_bwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_p]),
     'acktr_optim_workspace_bytes': (c_l, []),
     'acktr_clip_adam_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_clip_adam_dev_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p]),
+    'acktr_clip_adam_dev_head_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, ctypes.POINTER(HeadFin), c_p, c_p]),
     'acktr_clip_rmsprop_f32': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_sgd_momentum_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_i, c_p]),
     'acktr_kfac_cov_workspace_bytes': (c_l, [c_i, c_l]),

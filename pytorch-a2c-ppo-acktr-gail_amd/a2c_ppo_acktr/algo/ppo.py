@@ -6,12 +6,16 @@ categorical/gaussian + clipped-surrogate loss kernel that also emits the backwar
 into the flat gradient bucket -> [RCCL all-reduce] -> clip-norm + Adam in two launches.  Nothing syncs
 with the host until the three averaged losses are read back once at the end of `update`.
 """
+import ctypes
 import os
 
 import torch
 
 from .. import _hip, engine, ops
 from ..parallel import DataParallel
+
+# ACKTR_DEFER_HEAD=0: the head step finalizes in its own launch (comparison switch)
+DEFER_HEAD_FINALIZE = os.environ.get('ACKTR_DEFER_HEAD', '1') != '0'
 
 
 class _FlatAdam(object):
@@ -49,14 +53,22 @@ class _FlatAdam(object):
         """Host-side refresh of the device hyper-parameters; call outside graph capture."""
         self._state()
 
-    def step(self, max_grad_norm=None, capturing=False):
-        """clip_grad_norm_(max_grad_norm) (if given) + Adam step on the flat buffers."""
+    def step(self, max_grad_norm=None, capturing=False, pending=None):
+        """clip_grad_norm_(max_grad_norm) (if given) + Adam step on the flat buffers.  `pending`: a head step's deferred
+        finalize (engine.head_step(defer_finalize=True)), carried by the norm launch."""
         if not capturing:
             self._state()
         self.step_count += 1
         flat, gflat = self.policy.flat_params, self.policy.flat_grads
         L = _hip.lib()
         ws = ops.workspace(flat.device, L.acktr_optim_workspace_bytes(), 'optim')
+        if pending is not None:
+            rc = L.acktr_clip_adam_dev_head_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
+                                                _hip.dev_ptr(self.exp_avg_sq), flat.numel(), float(max_grad_norm),
+                                                _hip.dev_ptr(self.hyper_dev), _hip.dev_ptr(self.step_dev, torch.int32),
+                                                ctypes.byref(pending), _hip.dev_ptr(ws), _hip.cur_stream(flat.device))
+            _hip.check(rc, 'acktr_clip_adam_dev_head_f32')
+            return
         rc = L.acktr_clip_adam_dev_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
                                        _hip.dev_ptr(self.exp_avg_sq), flat.numel(),
                                        float(max_grad_norm) if max_grad_norm else 0.0, _hip.dev_ptr(self.hyper_dev),
@@ -122,21 +134,27 @@ class PPO():
         fuse_head = b.get('hxs') is None and engine.head_step_ok(ac, nrows)
         acts = engine.forward(ac, b['obs'], gather_idx=b['idx'], rnn_hxs=b.get('hxs'), masks=b.get('masks'),
                               head=not fuse_head)
-        (engine.head_step if fuse_head else engine.policy_loss)(
+        # single process, clipped: the head's slab sums ride in the optimiser's norm launch (one launch fewer per step)
+        defer = bool(fuse_head and with_optimizer and self.max_grad_norm and DEFER_HEAD_FINALIZE)
+        ret = (engine.head_step if fuse_head else engine.policy_loss)(
             ac, acts, engine.ALGO_PPO, b['actions'], b['loss_acc'], b['inv_batch'],
             old_logp=b['old_logp'], old_values=b['old_values'], returns=b['returns'], adv=b['adv'],
             gather_idx=b['idx'], clip=self.clip_param, value_coef=self.value_loss_coef,
-            entropy_coef=self.entropy_coef, use_clipped_value_loss=self.use_clipped_value_loss)
+            entropy_coef=self.entropy_coef, use_clipped_value_loss=self.use_clipped_value_loss,
+            **(dict(defer_finalize=True) if defer else {}))
+        self._pending = ret if defer else None
         engine.backward(ac, acts, ac.flat_grads, phase=phase)
         self._acts = acts if phase == 1 else None
         return False
 
     def _step(self, b, capturing=False):
         """one single-process minibatch step: forward, loss, backward, clip + Adam (ppo.py:57-84)"""
+        self._pending = None
         if self._fwd_bwd(b, with_optimizer=True):
             self.optimizer.step_count += 1
         else:
-            self.optimizer.step(self.max_grad_norm, capturing=capturing)
+            self.optimizer.step(self.max_grad_norm, capturing=capturing, pending=self._pending)
+            self._pending = None
 
     def _dp_step(self, b, split, graphs, capturing=False):
         """One data-parallel minibatch step: (phase 1) -> start all-reduce of grads[split:] -> (phase 2) -> all-reduce

@@ -428,9 +428,12 @@ def head_step_ok(policy, B):
 
 def head_step(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, old_values=None, returns=None, adv=None,
               gather_idx=None, clip=0.0, value_coef=0.0, entropy_coef=0.0, use_clipped_value_loss=True, gflat=None,
-              logp_out=None):
+              logp_out=None, defer_finalize=False):
     """After forward(..., head=False): fills acts.head / acts.dhead / acts.dfeat_fused, writes the head's weight and
-    bias gradients into `gflat` and adds this batch's (value_loss, action_loss, entropy) to loss_acc."""
+    bias gradients into `gflat` and adds this batch's (value_loss, action_loss, entropy) to loss_acc.
+    defer_finalize: the slab sums behind the head gradients and the loss are left pending and RETURNED (_hip.HeadFin)
+    for the optimiser's norm launch to carry (`_FlatAdam.step(pending=...)`): until then gflat's head ranges and
+    loss_acc are stale -- only for a caller that runs that optimiser step next on the same stream."""
     feat = acts.head_in
     dev = feat.device
     B, H = feat.shape
@@ -456,11 +459,17 @@ def head_step(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, o
     args.loss_acc = p(loss_acc)
     ws = ops.workspace(dev, L.acktr_head_step_workspace_bytes(B, H, A), 'head')
     args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
+    pending = _hip.HeadFin() if defer_finalize else None
     with ops._Timed('head%dx%d_step' % (H, 1 + A), 6.0 * B * H * (1 + A)):
-        rc = L.acktr_head_step_f32(ctypes.byref(args), p(feat), p(wh.detach()), p(bh.detach()), p(dfeat), p(gwh), p(gbh),
-                                   H, _hip.cur_stream(dev))
+        if pending is not None:
+            rc = L.acktr_head_step_deferred_f32(ctypes.byref(args), p(feat), p(wh.detach()), p(bh.detach()), p(dfeat),
+                                                p(gwh), p(gbh), H, ctypes.byref(pending), _hip.cur_stream(dev))
+        else:
+            rc = L.acktr_head_step_f32(ctypes.byref(args), p(feat), p(wh.detach()), p(bh.detach()), p(dfeat), p(gwh),
+                                       p(gbh), H, _hip.cur_stream(dev))
     _hip.check(rc, 'acktr_head_step_f32')
     acts.dfeat_fused = dfeat
+    return pending
 
 
 # ----------------------------------------------------------------------------------------------

@@ -12,6 +12,7 @@
 // weight gradient; the 1+A dot products are butterfly-reduced (every lane ends with the same head row, so the loss
 // arithmetic is wave-uniform).
 #include "loss_terms.hpp"
+#include "head_finalize.hpp"
 #include "../../include/acktr_hip.h"
 
 namespace acktr {
@@ -201,35 +202,8 @@ __global__ __launch_bounds__(256) void head_step_kernel(acktr_loss_args a, const
     if (lane < HS_TAIL) slab[(long)OUT * HS_H + lane] = ((tail[0][lane] + tail[1][lane]) + tail[2][lane]) + tail[3][lane];
 }
 
-// Fixed-order sum of the workgroup slabs: eight lanes share one float4 column (slab s goes to lane group s % 8), then a
-// three-step butterfly.  Element e of a slab: e < nw -> dW[e]; nw <= e < nw+8 -> db; nw+8.. -> the three loss sums.
-__global__ __launch_bounds__(256) void head_finalize_kernel(const float* __restrict__ slabs, int nb, long stride, int n4, int nw,
-                                                            int OUT, float* __restrict__ gw, float* __restrict__ gb,
-                                                            float* __restrict__ loss_acc, float inv_batch) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int i = (blockIdx.x * 4 + wave) * 8 + (lane & 7), sub = lane >> 3;
-    hf4 acc = hf4{0.f, 0.f, 0.f, 0.f};
-    if (i < n4) {
-#pragma unroll 4
-        for (int s = sub; s < nb; s += 8) acc += *reinterpret_cast<const hf4*>(slabs + (long)s * stride + 4 * i);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float v = acc[j];
-        v += __shfl_xor(v, 8, 64);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[j] = v;
-    }
-    if (sub != 0 || i >= n4) return;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int e = 4 * i + j;
-        if (e < nw) gw[e] = acc[j];
-        else if (e < nw + 8) { if (gb && e - nw < OUT) gb[e - nw] = acc[j]; }
-        else if (e < nw + 11) { if (loss_acc) loss_acc[e - nw - 8] += acc[j] * inv_batch; }
-    }
-}
+// Fixed-order sum of the workgroup slabs (head_finalize.hpp)
+__global__ __launch_bounds__(256) void head_finalize_kernel(const acktr_head_fin f) { (void)head_finalize_block(f, blockIdx.x); }
 
 static int head_slabs(int B) {
     int nb = cdiv(B, HS_ROWS);
@@ -248,8 +222,8 @@ extern "C" long acktr_head_step_workspace_bytes(int B, int H, int A) {
     return (long)head_slabs(B) * ((long)(1 + A) * H + HS_TAIL) * (long)sizeof(float);
 }
 
-extern "C" int acktr_head_step_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh,
-                                   float* dfeat, float* dwh, float* dbh, int H, void* stream) {
+static int head_step_launch(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh, float* dfeat,
+                            float* dwh, float* dbh, int H, void* stream, acktr_head_fin* defer) {
     ACKTR_ARG(args, "head_step: null args");
     const acktr_loss_args& a = *args;
     ACKTR_ARG(acktr_head_step_supported(a.B, H, a.A, a.dist), "head_step: unsupported shape B=%d H=%d A=%d dist=%d", a.B, H,
@@ -271,9 +245,23 @@ extern "C" int acktr_head_step_f32(const acktr_loss_args* args, const float* fea
     else if (a.algo == 1) hipLaunchKernelGGL((head_step_kernel<1>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT);
     else hipLaunchKernelGGL((head_step_kernel<2>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT);
     ACKTR_LAUNCH_CHECK();
-    const int n4 = (int)(stride / 4);
-    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv(n4, 32)), dim3(256), 0, s, (const float*)slabs, nb, stride, n4, OUT * H,
-                       OUT, dwh, dbh, a.loss_acc, a.inv_batch);
+    acktr_head_fin f;
+    f.slabs = slabs; f.nb = nb; f.stride = stride; f.n4 = (int)(stride / 4); f.nw = OUT * H; f.OUT = OUT;
+    f.gw = dwh; f.gb = dbh; f.loss_acc = a.loss_acc; f.inv_batch = a.inv_batch;
+    if (defer) { *defer = f; return 0; }
+    hipLaunchKernelGGL(head_finalize_kernel, dim3(cdiv(f.n4, 32)), dim3(256), 0, s, f);
     ACKTR_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int acktr_head_step_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh,
+                                   float* dfeat, float* dwh, float* dbh, int H, void* stream) {
+    return head_step_launch(args, feat, wh, bh, dfeat, dwh, dbh, H, stream, nullptr);
+}
+
+extern "C" int acktr_head_step_deferred_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh,
+                                            float* dfeat, float* dwh, float* dbh, int H, acktr_head_fin* pending,
+                                            void* stream) {
+    ACKTR_ARG(pending && dbh, "head_step_deferred: null pointer");
+    return head_step_launch(args, feat, wh, bh, dfeat, dwh, dbh, H, stream, pending);
 }

@@ -9,6 +9,7 @@
 //   torch/optim/rmsprop.py:316-339               single-tensor RMSprop (not centred, no momentum)
 //   torch/optim/sgd.py:358-380                   SGD with momentum (first step: buf = grad)
 #include "optim_terms.hpp"
+#include "head_finalize.hpp"
 #include "../../include/acktr_hip.h"
 
 namespace acktr {
@@ -25,6 +26,28 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const float*
     for (long i = (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
         const double x = (double)g[i];
         s += x * x;
+    }
+    s = block_sum(s, sm);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// The same partials with a pending head finalize (acktr_head_step_deferred_f32) riding in the launch: workgroups
+// [0, nfin) sum the head step's slabs into dwh / dbh (which lie inside g) and report the squares of what they wrote;
+// the others walk g and leave those two ranges out.  One dependent launch fewer per minibatch step.
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_head_kernel(const float* g, long n, double* partial, int* bump,
+                                                                 const acktr_head_fin f, int nfin, long w0, long b0) {
+    __shared__ double sm[16];
+    double s = 0.0;
+    if ((int)blockIdx.x < nfin) {
+        s = head_finalize_block(f, blockIdx.x);
+    } else {
+        const int blk = blockIdx.x - nfin, nblk = gridDim.x - nfin;
+        if (bump && blk == 0 && threadIdx.x == 0) *bump = *bump + 1;
+        for (long i = (long)blk * OPT_THREADS + threadIdx.x; i < n; i += (long)nblk * OPT_THREADS) {
+            if ((i >= w0 && i < w0 + f.nw) || (i >= b0 && i < b0 + f.OUT)) continue;
+            const double x = (double)g[i];
+            s += x * x;
+        }
     }
     s = block_sum(s, sm);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
@@ -205,6 +228,32 @@ extern "C" int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_a
     }
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
                        (const double*)workspace, nb, use_clip, max_grad_norm, 0.f, 0.f, 0.f, 0.f, 1.f, (float*)nullptr,
+                       hyper_dev, (const int*)step_dev);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int acktr_clip_adam_dev_head_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                            float max_grad_norm, const float* hyper_dev, int* step_dev,
+                                            const acktr_head_fin* pending, void* workspace, void* stream) {
+    ACKTR_ARG(params && grads && exp_avg && exp_avg_sq && workspace && hyper_dev && step_dev && pending,
+              "clip_adam_dev_head: null pointer");
+    ACKTR_ARG(n > 0 && max_grad_norm > 0.f, "clip_adam_dev_head: needs n > 0 and a clip norm (the finalize rides in the norm launch)");
+    const acktr_head_fin& f = *pending;
+    ACKTR_ARG(f.slabs && f.gw && f.gb && f.nb > 0 && f.n4 > 0 && f.nw > 0 && f.OUT > 0 && f.OUT <= 8,
+              "clip_adam_dev_head: incomplete pending finalize");
+    ACKTR_ARG(f.gw >= grads && f.gw + f.nw <= grads + n && f.gb >= grads && f.gb + f.OUT <= grads + n,
+              "clip_adam_dev_head: the head gradients must lie inside the flat gradient buffer");
+    hipStream_t s = (hipStream_t)stream;
+    const int nfin = cdiv(f.n4, 32);
+    ACKTR_ARG(nfin < OPT_MAX_PARTIALS / 2, "clip_adam_dev_head: head too large");
+    int nb = grid_for(n);
+    if (nb + nfin > OPT_MAX_PARTIALS) nb = OPT_MAX_PARTIALS - nfin;
+    hipLaunchKernelGGL(sumsq_head_kernel, dim3(nb + nfin), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace, step_dev, f,
+                       nfin, (long)(f.gw - grads), (long)(f.gb - grads));
+    ACKTR_LAUNCH_CHECK();
+    hipLaunchKernelGGL((clip_update_kernel<0>), dim3(grid_for(n)), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
+                       (const double*)workspace, nb + nfin, 1, max_grad_norm, 0.f, 0.f, 0.f, 0.f, 1.f, (float*)nullptr,
                        hyper_dev, (const int*)step_dev);
     ACKTR_LAUNCH_CHECK();
     return 0;

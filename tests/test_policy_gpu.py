@@ -147,6 +147,37 @@ def test_ppo_update_vs_reference(ci):
             check_summary(G, tag + '/update%d/param/%s' % (it, n), p.detach().cpu().numpy(), TOL, tag)
 
 
+def test_ppo_deferred_head_finalize_matches_own_launch():
+    """The head step's slab sums carried by the optimiser's norm launch (the default single-process PPO step,
+    acktr_head_step_deferred_f32 + acktr_clip_adam_dev_head_f32) against the same sums in a launch of their own: three
+    updates each (the third replays the captured epoch graph), same losses and parameters up to the regrouping of the
+    fp64 norm partials."""
+    from a2c_ppo_acktr import algo
+    from a2c_ppo_acktr.algo import ppo as ppo_mod
+    ci = [i for i, c in enumerate(PPO_CASES) if c[1] == 'cnn'][0]
+    tag, kind, od, A, T, N, hp = PPO_CASES[ci]
+    assert hp.get('max_grad_norm'), 'the deferred finalize rides in the clip-norm launch'
+    ro = synth.make_rollouts(T, N, (4, 84, 84), 'discrete', A, salt=733)
+    out = {}
+    saved = ppo_mod.DEFER_HEAD_FINALIZE
+    try:
+        for defer in (True, False):
+            ppo_mod.DEFER_HEAD_FINALIZE = defer
+            pol = make_policy(kind, od, A, 61)
+            rs = make_storage(ro, (4, 84, 84), Discrete(A))
+            rs.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
+            agent = algo.PPO(pol, **hp)
+            losses = []
+            for it in range(3):
+                torch.manual_seed(99 + it)
+                losses.append(agent.update(rs))
+            out[defer] = (np.array(losses), pol.flat_params.detach().cpu().numpy().copy())
+    finally:
+        ppo_mod.DEFER_HEAD_FINALIZE = saved
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=2e-7)
+
+
 @pytest.mark.parametrize('ci', range(len(A2C_CASES)))
 def test_a2c_update_vs_reference(ci):
     """Losses: 1e-4 vs the reference golden on every update.  Parameters: 1e-4 after the first update.

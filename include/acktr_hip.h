@@ -86,6 +86,18 @@ long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, int OC, int 
 int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw, float* db, int B,
                            int C, int H, int W, int OC, int KH, int KW, int S, float in_scale, void* workspace,
                            long workspace_bytes, void* stream);
+/* A weight gradient whose workgroup slabs are written but not yet summed: dst[0 .. 4*n4) = scale * sum over the nslabs
+ * slabs (stride floats apart) in the fixed order of the stand-alone reduction.  dst == NULL: nothing pending. */
+typedef struct acktr_slab_fin {
+    float* dst; const float* slabs; int nslabs; long n4; long stride; float scale;
+} acktr_slab_fin;
+/* The same weight gradient with its final slab sum left PENDING when the layer runs the stationary-accumulator kernel
+ * whose slabs one launch can sum and db directly follows dw (the policy's conv1 at minibatches >= 256): `*pending`
+ * then describes it for acktr_clip_adam_dev_head_f32 and dw / db are NOT complete until that call; otherwise the call
+ * completes as acktr_conv2d_wgrad_f32 does and pending->dst is NULL.  No counterpart in the reference. */
+int acktr_conv2d_wgrad_deferred_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw, float* db,
+                                    int B, int C, int H, int W, int OC, int KH, int KW, int S, float in_scale,
+                                    void* workspace, long workspace_bytes, acktr_slab_fin* pending, void* stream);
 
 /* autograd backward w.r.t. the input: dx[B,C,H,W] = conv_transpose(dy, w) (* (x_act > 0) when x_act is
  * given: the ReLU backward of the layer that produced x, model.py:177-179).  `workspace` (16-byte aligned,
@@ -233,11 +245,14 @@ int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, float* exp_
  * (bias corrections evaluated in double on the device).  No counterpart in the reference (host loop there). */
 int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n, float max_grad_norm,
                             const float* hyper_dev, int* step_dev, void* workspace, void* stream);
-/* acktr_clip_adam_dev_f32 with a pending head finalize (acktr_head_step_deferred_f32) carried in the norm launch; dwh and
- * dbh of `pending` must lie inside `grads`; max_grad_norm > 0 required. */
+/* acktr_clip_adam_dev_f32 with pending reductions carried in the norm launch: a head finalize
+ * (acktr_head_step_deferred_f32) and / or a weight-gradient slab sum (acktr_conv2d_wgrad_deferred_f32); either may be
+ * NULL (or, for `slab`, hold dst == NULL: nothing pending).  Their destinations must lie inside `grads`;
+ * max_grad_norm > 0 required. */
 int acktr_clip_adam_dev_head_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
                                  float max_grad_norm, const float* hyper_dev, int* step_dev,
-                                 const acktr_head_fin* pending, void* workspace, void* stream);
+                                 const acktr_head_fin* pending, const acktr_slab_fin* slab, void* workspace,
+                                 void* stream);
 /* clip_grad_norm_ + optim.RMSprop.step -- algo/a2c_acktr.py:74-78 (torch/optim/rmsprop.py:316-339). */
 int acktr_clip_rmsprop_f32(float* params, float* grads, float* square_avg, long n, float max_grad_norm, float lr,
                            float alpha, float eps, float* total_norm_out, void* workspace, void* stream);

@@ -65,6 +65,11 @@ class HeadFin(ctypes.Structure):
                 ('gw', c_p), ('gb', c_p), ('loss_acc', c_p), ('inv_batch', c_f)]
 
 
+class SlabFin(ctypes.Structure):
+    """struct acktr_slab_fin (include/acktr_hip.h): a weight gradient's pending slab sum"""
+    _fields_ = [('dst', c_p), ('slabs', c_p), ('nslabs', c_i), ('n4', c_l), ('stride', c_l), ('scale', c_f)]
+
+
 class PrecondJob(ctypes.Structure):
     """struct acktr_precond_job (include/acktr_hip.h)"""
     _fields_ = [('grad', c_p), ('qt_g', c_p), ('d_g', c_p), ('qt_a', c_p), ('d_a', c_p), ('tmp1', c_p), ('tmp2', c_p),
@@ -91,6 +96,8 @@ _PROTOS = {
     'acktr_conv2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_i, c_p, c_l, c_i, c_p]),
     'acktr_conv2d_wgrad_workspace_bytes': (c_l, [c_i] * 8),
     'acktr_conv2d_wgrad_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_p, c_l, c_p]),
+    'acktr_conv2d_wgrad_deferred_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_p, c_l, ctypes.POINTER(SlabFin),
+                                              c_p]),
     'acktr_conv2d_dgrad_workspace_bytes': (c_l, [c_i] * 8),
     'acktr_conv2d_dgrad_f32': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_l, c_i, c_p]),
     'acktr_conv2d_dgrad_padded_dy_offset_bytes': (c_l, [c_i] * 7),
@@ -116,7 +123,8 @@ _PROTOS = {
     'acktr_optim_workspace_bytes': (c_l, []),
     'acktr_clip_adam_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_clip_adam_dev_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p]),
-    'acktr_clip_adam_dev_head_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, ctypes.POINTER(HeadFin), c_p, c_p]),
+    'acktr_clip_adam_dev_head_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, ctypes.POINTER(HeadFin),
+                                           ctypes.POINTER(SlabFin), c_p, c_p]),
     'acktr_clip_rmsprop_f32': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_sgd_momentum_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_i, c_p]),
     'acktr_kfac_cov_workspace_bytes': (c_l, [c_i, c_l]),

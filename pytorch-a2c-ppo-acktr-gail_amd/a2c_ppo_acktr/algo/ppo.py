@@ -53,20 +53,23 @@ class _FlatAdam(object):
         """Host-side refresh of the device hyper-parameters; call outside graph capture."""
         self._state()
 
-    def step(self, max_grad_norm=None, capturing=False, pending=None):
+    def step(self, max_grad_norm=None, capturing=False, pending=None, slab=None):
         """clip_grad_norm_(max_grad_norm) (if given) + Adam step on the flat buffers.  `pending`: a head step's deferred
-        finalize (engine.head_step(defer_finalize=True)), carried by the norm launch."""
+        finalize (engine.head_step(defer_finalize=True)), `slab`: the last weight gradient's deferred slab sum
+        (engine.backward(defer_last=...)); both are carried by the norm launch."""
         if not capturing:
             self._state()
         self.step_count += 1
         flat, gflat = self.policy.flat_params, self.policy.flat_grads
         L = _hip.lib()
         ws = ops.workspace(flat.device, L.acktr_optim_workspace_bytes(), 'optim')
-        if pending is not None:
+        if pending is not None or slab is not None:
             rc = L.acktr_clip_adam_dev_head_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
                                                 _hip.dev_ptr(self.exp_avg_sq), flat.numel(), float(max_grad_norm),
                                                 _hip.dev_ptr(self.hyper_dev), _hip.dev_ptr(self.step_dev, torch.int32),
-                                                ctypes.byref(pending), _hip.dev_ptr(ws), _hip.cur_stream(flat.device))
+                                                ctypes.byref(pending) if pending is not None else None,
+                                                ctypes.byref(slab) if slab is not None else None,
+                                                _hip.dev_ptr(ws), _hip.cur_stream(flat.device))
             _hip.check(rc, 'acktr_clip_adam_dev_head_f32')
             return
         rc = L.acktr_clip_adam_dev_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
@@ -143,18 +146,19 @@ class PPO():
             entropy_coef=self.entropy_coef, use_clipped_value_loss=self.use_clipped_value_loss,
             **(dict(defer_finalize=True) if defer else {}))
         self._pending = ret if defer else None
-        engine.backward(ac, acts, ac.flat_grads, phase=phase)
+        self._pending_slab = _hip.SlabFin() if defer else None
+        engine.backward(ac, acts, ac.flat_grads, phase=phase, defer_last=self._pending_slab)
         self._acts = acts if phase == 1 else None
         return False
 
     def _step(self, b, capturing=False):
         """one single-process minibatch step: forward, loss, backward, clip + Adam (ppo.py:57-84)"""
-        self._pending = None
+        self._pending = self._pending_slab = None
         if self._fwd_bwd(b, with_optimizer=True):
             self.optimizer.step_count += 1
         else:
-            self.optimizer.step(self.max_grad_norm, capturing=capturing, pending=self._pending)
-            self._pending = None
+            self.optimizer.step(self.max_grad_norm, capturing=capturing, pending=self._pending, slab=self._pending_slab)
+            self._pending = self._pending_slab = None
 
     def _dp_step(self, b, split, graphs, capturing=False):
         """One data-parallel minibatch step: (phase 1) -> start all-reduce of grads[split:] -> (phase 2) -> all-reduce

@@ -288,13 +288,15 @@ def late_bucket_offset(policy):
     return off
 
 
-def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None):
+def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None, defer_last=None):
     """Parameter gradients of one batch into the flat gradient buffer `gflat` (overwrites, never
     accumulates).  phase (NatureCNN only): None = everything; 1 = head, FC and conv3 gradients (everything at or
     behind late_bucket_offset()); 2 = the rest, continuing from what phase 1 left on `acts`.  With keep=True the pre-activation gradients of every layer stay on `acts`
     (dy1, dy2, dy3, dfeat / dhc*, dha*) -- the `grad_output`s KFAC's backward hooks would see.
     wgrad=False runs the data-gradient chain only (the sampled-Fisher pass of ACKTR needs no
     parameter gradients, a2c_acktr.py:66-70).
+    defer_last (a _hip.SlabFin, NatureCNN only): the LAST weight gradient (conv1) may leave its slab sum to the optimiser's
+    norm launch, see ops.conv2d_wgrad.
     (Measured and dropped: issuing the weight-gradient launches on a second stream -- a parallel branch of the
     captured graph -- to fill the dispatch bubbles of the data-gradient chain.  11.63 ms per update became 12.51
     with every wgrad on the side stream and 11.70-11.75 with only the head / FC ones: the big kernels each fill
@@ -342,7 +344,7 @@ def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None):
         dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2, packed=acts.packs.get('d2'), dy_prepadded=pd2 is not None)
         if wgrad:
             ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1),
-                             in_scale=1.0 / 255.0, gather_idx=acts.idx)
+                             in_scale=1.0 / 255.0, gather_idx=acts.idx, pending=defer_last)
         if keep:
             acts.dfeat, acts.dy3, acts.dy2, acts.dy1 = dfeat, dy3, dy2, dy1
         return

@@ -4,6 +4,7 @@ Thin plumbing only: shape checks on the host (a wrong shape must never reach a
 kernel), device pointers + the current stream handed to the library.  Every
 function requires fp32 contiguous GPU tensors and raises otherwise.
 """
+import ctypes
 import torch
 
 from . import _hip
@@ -136,7 +137,10 @@ def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out
     return out
 
 
-def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=None):
+def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=None, pending=None):
+    """pending (a _hip.SlabFin): the final slab sum may be left to the optimiser's norm launch
+    (acktr_conv2d_wgrad_deferred_f32); pending.dst is None afterwards when the call completed on its own.  The slabs
+    live in the shared workspace: nothing else may use it before that optimiser call."""
     OC, C, KH, KW = w_shape
     H, W = x.shape[-2], x.shape[-1]
     B = dy.shape[0]
@@ -150,10 +154,16 @@ def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=N
     nbytes = L.acktr_conv2d_wgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride)
     ws = workspace(x.device, nbytes)
     with _Timed('conv%ds%d_wgrad' % (KH, stride), 2.0 * dy[0].numel() * B * C * KH * KW):
-        rc = L.acktr_conv2d_wgrad_f32(
-            _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(dy, 'dy'), _p(dw, 'dw'), _p(db, 'db'),
-            B, C, H, W, OC, KH, KW, stride, float(in_scale), _p(ws, 'workspace', torch.uint8), ws.numel(),
-            _hip.cur_stream(x.device))
+        if pending is not None:
+            rc = L.acktr_conv2d_wgrad_deferred_f32(
+                _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(dy, 'dy'), _p(dw, 'dw'), _p(db, 'db'),
+                B, C, H, W, OC, KH, KW, stride, float(in_scale), _p(ws, 'workspace', torch.uint8), ws.numel(),
+                ctypes.byref(pending), _hip.cur_stream(x.device))
+        else:
+            rc = L.acktr_conv2d_wgrad_f32(
+                _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(dy, 'dy'), _p(dw, 'dw'), _p(db, 'db'),
+                B, C, H, W, OC, KH, KW, stride, float(in_scale), _p(ws, 'workspace', torch.uint8), ws.numel(),
+                _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_conv2d_wgrad_f32')
 
 

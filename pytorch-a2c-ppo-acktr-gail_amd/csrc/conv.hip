@@ -136,7 +136,7 @@ static int sa1_wgrad_slabs(int B) {
     return by_work < cus ? (by_work < 1 ? 1 : by_work) : cus;
 }
 static int conv1_wgrad_sa(const float* x, const int64_t* idx, const float* dy, float* dw, float* db, int B, float scale,
-                          float* ws, long ws_floats, hipStream_t s) {
+                          float* ws, long ws_floats, hipStream_t s, acktr_slab_fin* defer = nullptr) {
     const long wk = (long)S1_OC * S1_KC, slab = wk + S1_OC;
     const int ns = sa1_wgrad_slabs(B);
     if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
@@ -149,6 +149,11 @@ static int conv1_wgrad_sa(const float* x, const int64_t* idx, const float* dy, f
     }
     hipLaunchKernelGGL(conv1_wgrad_sa_kernel, dim3(ns), dim3(64 * S1_WAVES), S1_LDS_BYTES, s, x, idx, dy, ws, slab, B, scale);
     ACKTR_LAUNCH_CHECK();
+    if (defer && db == dw + wk && ns >= 16 && (((uintptr_t)dw | (uintptr_t)ws) & 15) == 0) {   // (what slab_reduce_wave_kernel serves)
+        defer->dst = dw; defer->slabs = ws; defer->nslabs = ns; defer->n4 = (wk + S1_OC) / 4; defer->stride = slab;
+        defer->scale = 1.f;
+        return 0;
+    }
     if (db == dw + wk) return launch_slab_reduce(dw, ws, ns, wk + S1_OC, slab, 1.f, 0, s);
     int rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
     if (rc || !db) return rc;
@@ -381,9 +386,9 @@ extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, i
     return (long)(ns + SLAB_GROUP_EXTRA) * wgrad_slab_floats(OC, Kc) * (long)sizeof(float);
 }
 
-extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw,
-                                      float* db, int B, int C, int H, int W, int OC, int KH, int KW, int S,
-                                      float in_scale, void* workspace, long workspace_bytes, void* stream) {
+static int conv2d_wgrad_impl(const float* x, const int64_t* gather_idx, const float* dy, float* dw,
+                             float* db, int B, int C, int H, int W, int OC, int KH, int KW, int S,
+                             float in_scale, void* workspace, long workspace_bytes, void* stream, acktr_slab_fin* defer) {
     ACKTR_ARG(x && dy && dw, "conv2d_wgrad: null pointer");
     const bool gather_ok = true;
     CONV_COMMON_CHECKS("conv2d_wgrad");
@@ -395,7 +400,7 @@ extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx,
     (OC <= 32 ? conv_wgrad_t<KH_, KW_, S_, H_, W_, 32, 1, 4>(x, gather_idx, dy, dw, db, B, C, OC, in_scale, ws, wf, s) \
               : conv_wgrad_t<KH_, KW_, S_, H_, W_, 64, 2, 2>(x, gather_idx, dy, dw, db, B, C, OC, in_scale, ws, wf, s))
     if (sa1_wgrad_ok(geom, C, OC, B)) {
-        const int rc = conv1_wgrad_sa(x, gather_idx, dy, dw, db, B, in_scale, ws, wf, s);
+        const int rc = conv1_wgrad_sa(x, gather_idx, dy, dw, db, B, in_scale, ws, wf, s, defer);
         if (rc != -2) return rc;
     }
     if (sa2_wgrad_ok(geom, C, OC, B, gather_idx)) {
@@ -424,6 +429,23 @@ static long dgrad_ws_floats(int B, int C, int H, int W, int OC, int KH, int KW, 
         if (m > n) n = m;
     }
     return n;
+}
+
+extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw,
+                                      float* db, int B, int C, int H, int W, int OC, int KH, int KW, int S,
+                                      float in_scale, void* workspace, long workspace_bytes, void* stream) {
+    return conv2d_wgrad_impl(x, gather_idx, dy, dw, db, B, C, H, W, OC, KH, KW, S, in_scale, workspace, workspace_bytes, stream,
+                             nullptr);
+}
+
+extern "C" int acktr_conv2d_wgrad_deferred_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw,
+                                               float* db, int B, int C, int H, int W, int OC, int KH, int KW, int S,
+                                               float in_scale, void* workspace, long workspace_bytes,
+                                               acktr_slab_fin* pending, void* stream) {
+    ACKTR_ARG(pending, "conv2d_wgrad_deferred: null pending");
+    pending->dst = nullptr;
+    return conv2d_wgrad_impl(x, gather_idx, dy, dw, db, B, C, H, W, OC, KH, KW, S, in_scale, workspace, workspace_bytes, stream,
+                             pending);
 }
 
 extern "C" long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, int OC, int KH, int KW, int S) {

@@ -39,4 +39,37 @@ __device__ __forceinline__ double head_finalize_block(const acktr_head_fin& f, i
     return sq;
 }
 
+// slab_reduce_wave_kernel's arithmetic (linear.hip: sixteen lanes share a float4 column, lane group `sub` sums slabs sub,
+// sub+16, ..., four-step butterfly) for a pending weight-gradient sum; `block` plays blockIdx.x of a 256-thread workgroup.
+// Returns the sum of squares of what this thread wrote.
+__device__ __forceinline__ double slab_finalize_block(const acktr_slab_fin& f, int block) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long i = ((long)block * 4 + wave) * 4 + (lane & 3);
+    const int sub = lane >> 2;
+    hfin4 acc = hfin4{0.f, 0.f, 0.f, 0.f};
+    if (i < f.n4) {
+#pragma unroll 8
+        for (int k = sub; k < f.nslabs; k += 16) acc = acc + *reinterpret_cast<const hfin4*>(f.slabs + (long)k * f.stride + 4 * i);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v = acc[j];
+        v += __shfl_xor(v, 4, 64);
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        acc[j] = v;
+    }
+    double sq = 0.0;
+    if (sub != 0 || i >= f.n4) return sq;
+    hfin4 res;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        res[j] = acc[j] * f.scale + 0.f;
+        sq += (double)res[j] * (double)res[j];
+    }
+    *reinterpret_cast<hfin4*>(f.dst + 4 * i) = res;
+    return sq;
+}
+
 }  // namespace acktr

@@ -31,20 +31,26 @@ __global__ __launch_bounds__(OPT_THREADS) void sumsq_partial_kernel(const float*
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
 }
 
-// The same partials with a pending head finalize (acktr_head_step_deferred_f32) riding in the launch: workgroups
-// [0, nfin) sum the head step's slabs into dwh / dbh (which lie inside g) and report the squares of what they wrote;
-// the others walk g and leave those two ranges out.  One dependent launch fewer per minibatch step.
-__global__ __launch_bounds__(OPT_THREADS) void sumsq_head_kernel(const float* g, long n, double* partial, int* bump,
-                                                                 const acktr_head_fin f, int nfin, long w0, long b0) {
+// The same partials with pending reductions riding in the launch (acktr_head_step_deferred_f32,
+// acktr_conv2d_wgrad_deferred_f32): workgroups [0, nfin) sum the head step's slabs into dwh / dbh, [nfin, nfin + nred) a
+// weight gradient's slabs into its dw | db -- all inside g -- and report the squares of what they wrote; the others walk
+// g and leave those ranges out.  One dependent launch fewer per pending reduction and minibatch step.
+__global__ __launch_bounds__(OPT_THREADS) void sumsq_fin_kernel(const float* g, long n, double* partial, int* bump,
+                                                                const acktr_head_fin f, int nfin, long w0, long b0,
+                                                                const acktr_slab_fin r, int nred, long r0) {
     __shared__ double sm[16];
     double s = 0.0;
+    const int npre = nfin + nred;
     if ((int)blockIdx.x < nfin) {
         s = head_finalize_block(f, blockIdx.x);
+    } else if ((int)blockIdx.x < npre) {
+        s = slab_finalize_block(r, blockIdx.x - nfin);
     } else {
-        const int blk = blockIdx.x - nfin, nblk = gridDim.x - nfin;
+        const int blk = blockIdx.x - npre, nblk = gridDim.x - npre;
         if (bump && blk == 0 && threadIdx.x == 0) *bump = *bump + 1;
+        const long wn = nfin ? f.nw : 0, bn = nfin ? f.OUT : 0, rn = nred ? 4 * r.n4 : 0;
         for (long i = (long)blk * OPT_THREADS + threadIdx.x; i < n; i += (long)nblk * OPT_THREADS) {
-            if ((i >= w0 && i < w0 + f.nw) || (i >= b0 && i < b0 + f.OUT)) continue;
+            if ((i >= w0 && i < w0 + wn) || (i >= b0 && i < b0 + bn) || (i >= r0 && i < r0 + rn)) continue;
             const double x = (double)g[i];
             s += x * x;
         }
@@ -235,25 +241,40 @@ extern "C" int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_a
 
 extern "C" int acktr_clip_adam_dev_head_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
                                             float max_grad_norm, const float* hyper_dev, int* step_dev,
-                                            const acktr_head_fin* pending, void* workspace, void* stream) {
-    ACKTR_ARG(params && grads && exp_avg && exp_avg_sq && workspace && hyper_dev && step_dev && pending,
-              "clip_adam_dev_head: null pointer");
-    ACKTR_ARG(n > 0 && max_grad_norm > 0.f, "clip_adam_dev_head: needs n > 0 and a clip norm (the finalize rides in the norm launch)");
-    const acktr_head_fin& f = *pending;
-    ACKTR_ARG(f.slabs && f.gw && f.gb && f.nb > 0 && f.n4 > 0 && f.nw > 0 && f.OUT > 0 && f.OUT <= 8,
-              "clip_adam_dev_head: incomplete pending finalize");
-    ACKTR_ARG(f.gw >= grads && f.gw + f.nw <= grads + n && f.gb >= grads && f.gb + f.OUT <= grads + n,
-              "clip_adam_dev_head: the head gradients must lie inside the flat gradient buffer");
+                                            const acktr_head_fin* pending, const acktr_slab_fin* slab, void* workspace,
+                                            void* stream) {
+    ACKTR_ARG(params && grads && exp_avg && exp_avg_sq && workspace && hyper_dev && step_dev, "clip_adam_dev_head: null pointer");
+    ACKTR_ARG(n > 0 && max_grad_norm > 0.f, "clip_adam_dev_head: needs n > 0 and a clip norm (the pending sums ride in the norm launch)");
+    acktr_head_fin f = {};
+    acktr_slab_fin r = {};
+    int nfin = 0, nred = 0;
+    if (pending) {
+        f = *pending;
+        ACKTR_ARG(f.slabs && f.gw && f.gb && f.nb > 0 && f.n4 > 0 && f.nw > 0 && f.OUT > 0 && f.OUT <= 8,
+                  "clip_adam_dev_head: incomplete pending finalize");
+        ACKTR_ARG(f.gw >= grads && f.gw + f.nw <= grads + n && f.gb >= grads && f.gb + f.OUT <= grads + n,
+                  "clip_adam_dev_head: the head gradients must lie inside the flat gradient buffer");
+        nfin = cdiv(f.n4, 32);
+    }
+    if (slab && slab->dst) {
+        r = *slab;
+        ACKTR_ARG(r.slabs && r.nslabs >= 16 && r.n4 > 0 && (r.stride & 3) == 0 && (((uintptr_t)r.dst | (uintptr_t)r.slabs) & 15) == 0,
+                  "clip_adam_dev_head: incomplete pending slab sum");
+        ACKTR_ARG(r.dst >= grads && r.dst + 4 * r.n4 <= grads + n,
+                  "clip_adam_dev_head: the pending weight gradient must lie inside the flat gradient buffer");
+        nred = (int)cdiv(r.n4, 16);
+    }
+    ACKTR_ARG(nfin + nred < OPT_MAX_PARTIALS / 2, "clip_adam_dev_head: pending reductions too large");
     hipStream_t s = (hipStream_t)stream;
-    const int nfin = cdiv(f.n4, 32);
-    ACKTR_ARG(nfin < OPT_MAX_PARTIALS / 2, "clip_adam_dev_head: head too large");
     int nb = grid_for(n);
-    if (nb + nfin > OPT_MAX_PARTIALS) nb = OPT_MAX_PARTIALS - nfin;
-    hipLaunchKernelGGL(sumsq_head_kernel, dim3(nb + nfin), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace, step_dev, f,
-                       nfin, (long)(f.gw - grads), (long)(f.gb - grads));
+    if (nb + nfin + nred > OPT_MAX_PARTIALS) nb = OPT_MAX_PARTIALS - nfin - nred;
+    const int total = nb + nfin + nred;
+    hipLaunchKernelGGL(sumsq_fin_kernel, dim3(total), dim3(OPT_THREADS), 0, s, grads, n, (double*)workspace, step_dev, f, nfin,
+                       nfin ? (long)(f.gw - grads) : 0L, nfin ? (long)(f.gb - grads) : 0L, r, nred,
+                       nred ? (long)(r.dst - grads) : 0L);
     ACKTR_LAUNCH_CHECK();
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(grid_for(n)), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
-                       (const double*)workspace, nb + nfin, 1, max_grad_norm, 0.f, 0.f, 0.f, 0.f, 1.f, (float*)nullptr,
+                       (const double*)workspace, total, 1, max_grad_norm, 0.f, 0.f, 0.f, 0.f, 1.f, (float*)nullptr,
                        hyper_dev, (const int*)step_dev);
     ACKTR_LAUNCH_CHECK();
     return 0;

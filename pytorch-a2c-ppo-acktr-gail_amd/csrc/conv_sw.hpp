@@ -440,9 +440,12 @@ int launch_conv_sw(const float* x, const int64_t* idx, const float* wimg, const 
             attr_set = true;
         }
     }
-    int grid = cdiv((long)ntiles * G::MG, G::NWAVES);
+    // one workgroup per CU, and never fewer workgroups than items allow: the partial round is dealt wave-major, so with
+    // fewer than 8 items per CU the items spread over all CUs (one or two waves each) instead of filling a few CUs with
+    // eight waves -- at 80 rows (the A2C update) conv2 / conv3 forward ran 2 items per SIMD on 16-51 CUs: 22 us each
+    long grid_l = (long)ntiles * G::MG;
     const int cus = sw_num_cus();
-    if (grid > cus) grid = cus;
+    const int grid = (int)(grid_l > cus ? cus : grid_l);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), smem_bytes, stream, x, idx, wimg, epi, R, ntiles);
     ACKTR_LAUNCH_CHECK();
     return 0;

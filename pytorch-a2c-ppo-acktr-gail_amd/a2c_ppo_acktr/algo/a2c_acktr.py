@@ -78,6 +78,7 @@ class A2C_ACKTR():
             return pg
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
+            self._loss_acc.zero_()                  # (a node of the graph: no launch of its own per update)
             self._update(rollouts, self._loss_acc)
         return g
 
@@ -112,7 +113,8 @@ class A2C_ACKTR():
             self._kgraphs[do_stats] = g
         if do_stats:
             self._noise_dev.copy_(torch.randn(T * N, 1))       # the draw accumulate_stats makes (a2c_acktr.py:59)
-        self._loss_acc.zero_()
+        if self.dp.active:                          # (single process: the graph zeroes it itself, _capture)
+            self._loss_acc.zero_()
         g.replay()
         opt.steps += 1
         vl, al, en = self._loss_acc.tolist()
@@ -135,7 +137,8 @@ class A2C_ACKTR():
             return self._update(rollouts, None)
         if self._graph is None:
             self._graph = self._capture(rollouts, rollouts.rewards.device)
-        self._loss_acc.zero_()
+        if self.dp.active:
+            self._loss_acc.zero_()
         self._graph.replay()
         vl, al, en = self._loss_acc.tolist()
         return vl, al, en

@@ -3,6 +3,10 @@
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: without a torch.distributed.run environment (no WORLD_SIZE) `--gpus N` starts its own N
+worker processes -- fresh children, started before this process has made any GPU call -- one rank per GPU over RCCL;
+rank 0 prints the JSON line, any failing rank makes the whole command exit non-zero.
+
 Workload (BASELINE.json configs[2], the configuration the metric "PPO ... update samples/sec (NatureCNN
 84x84x4) at 1/2/4/8 GPU" is quoted on): PPO, 4 epochs x 4 minibatches, T = 128 steps, 32 env processes PER
 GPU (256 processes at 8 GPUs = the top of the config's range), Categorical(6), synthetic uint8-valued frames
@@ -332,6 +336,93 @@ def side_metrics(device):
     return out
 
 
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(args, argv):
+    """`--gpus N` (N > 1) outside torch.distributed.run: start N worker processes of this script, one rank per GPU.
+    This process has made NO GPU call (torch.cuda.device_count() does not initialise the runtime on this image) and
+    never makes one: it only starts the children, forwards rank 0's stdout (the JSON line) and reaps them.  New in
+    this build -- the reference is single device (main.py:39).  Returns the exit code."""
+    import subprocess
+    n = args.gpus
+    if not args.launch_check:
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write('bench.py: --gpus %d needs %d GPUs, this machine exposes %d; nothing was started\n'
+                             % (n, n, have))
+            return 2
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+               HSA_ENABLE_IPC_MODE_LEGACY='0', ACKTR_BENCH_WORKER='1')
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=None if r == 0 else sys.stderr))
+    deadline = time.monotonic() + float(os.environ.get('ACKTR_BENCH_LAUNCH_TIMEOUT', '1500'))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 128 - c
+                sys.stderr.write('bench.py: rank %d exited with %d; stopping the other ranks\n' % (procs.index(p), c))
+        if rc != 0 or time.monotonic() > deadline:
+            if rc == 0:
+                rc = 124
+                sys.stderr.write('bench.py: ranks still running at the launcher deadline; stopping them\n')
+            for p in live:                      # exactly the children started above
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+            break
+        time.sleep(0.05)
+    return rc
+
+
+def dp_mode_string(world, backend_world):
+    """What the data-parallel PPO step runs as (a2c_ppo_acktr/algo/ppo.py): part of config.parallelism."""
+    g = os.environ.get('ACKTR_DP_GRAPH', '0')
+    ov = os.environ.get('ACKTR_DP_OVERLAP', '1') != '0'
+    if world == 1 and backend_world is None:
+        return 'dp1 (single process, one hipGraph per epoch, no collectives)'
+    step = {'0': 'eager launches', '1': 'hipGraph pieces around the collectives',
+            'full': 'one hipGraph per epoch with the RCCL all-reduces captured'}.get(g, g)
+    return 'dp%d (RCCL communicator of %s ranks; ACKTR_DP_GRAPH=%s: %s; late-bucket all-reduce %s)' % (
+        world, backend_world, g, step, 'overlapped with the backward' if ov else 'not overlapped')
+
+
+def launch_check(rank, world, json_fd):
+    """`--launch-check`: the launcher path up to the first device call, on gloo (CPU test of self_launch / the
+    torch.distributed.run environment): rendezvous, one SUM all-reduce, barrier, rank 0 prints one JSON line."""
+    import datetime
+    if os.environ.get('ACKTR_BENCH_TEST_FAIL_RANK') == str(rank):       # tests/test_parallel_cpu.py: a rank that dies
+        sys.exit(7)
+    dist.init_process_group('gloo', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    x = torch.tensor([float(rank + 1)])
+    dist.all_reduce(x)
+    ok = float(x.item()) == world * (world + 1) / 2
+    dist.barrier()
+    if rank == 0:
+        os.write(json_fd, (json.dumps(dict(launch_check=ok, world=dist.get_world_size(), backend='gloo',
+                                           sum=float(x.item()))) + '\n').encode())
+    dist.destroy_process_group()
+    return 0 if ok else 4
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -343,24 +434,48 @@ def main():
     ap.add_argument('--no-side-metrics', action='store_true')
     ap.add_argument('--force-dp', action='store_true',
                     help='one rank, but through the data-parallel code path on RCCL (rehearsal of the N>1 path)')
+    ap.add_argument('--launch-check', action='store_true',
+                    help='rendezvous + one all-reduce on gloo, no device call: tests the N-rank launcher on a CPU box')
     args = ap.parse_args()
 
-    # stdout carries exactly ONE line, the JSON record: everything else that lands on file descriptor 1 -- RCCL prints
-    # a version banner there from C when a communicator is created -- is sent to stderr for the rest of the run
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args, sys.argv[1:]))
+
+    # stdout carries exactly ONE line, the JSON record: everything else that lands on file descriptor 1 -- RCCL and
+    # gloo print banners there from C when a communicator is created -- is sent to stderr for the rest of the run
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    if args.launch_check:
+        sys.exit(launch_check(int(os.environ.get('RANK', '0')), int(os.environ.get('WORLD_SIZE', '1')), json_fd))
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        sys.stderr.write('bench.py: --gpus %d but the launcher environment says WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
+    have = torch.cuda.device_count()
+    if local_rank >= have:
+        sys.stderr.write('bench.py: rank %d wants cuda:%d, this machine exposes %d GPU(s)\n' % (rank, local_rank, have))
+        sys.exit(2)
+    rccl_world = None
     if world > 1 or args.force_dp:
+        import datetime
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29533')
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         torch.cuda.set_device(local_rank)
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
-    assert world == args.gpus, 'launch with torch.distributed.run --nproc-per-node %d' % args.gpus
+        # bounded rendezvous: a rank that never shows up is a failure record, not a hang
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank),
+                                timeout=datetime.timedelta(seconds=int(os.environ.get('ACKTR_BENCH_INIT_TIMEOUT', '300'))))
+        # the rank count the RCCL communicator itself reports, checked with one SUM all-reduce over it
+        probe = torch.ones(1, device='cuda:%d' % local_rank)
+        dist.all_reduce(probe)
+        rccl_world = int(probe.item())
+        if rccl_world != world or dist.get_world_size() != world:
+            sys.stderr.write('bench.py: RCCL communicator spans %d ranks, expected %d\n' % (rccl_world, world))
+            sys.exit(2)
     device = torch.device('cuda', local_rank)
     torch.cuda.set_device(device)
 
@@ -447,7 +562,7 @@ def main():
                    config=dict(workload='PPO.update NatureCNN 84x84x4 Categorical(6): T=128 x %d procs/GPU (%d global), '
                                         '4 epochs x 4 minibatches, fp32 MFMA' % (PROCS_PER_GPU, N_global),
                                global_batch=T_STEPS * N_global, minibatch=T_STEPS * N_global // PPO_HP['num_mini_batch'],
-                               parallelism='dp%d' % world),
+                               parallelism=dp_mode_string(world, rccl_world)),
                    roofline=roof,
                    whole_update=dict(mfma_tflops=round(samples_per_step * args.steps * FWD_BWD_FLOP_PER_SAMPLE / dt / 1e12 / world, 2),
                                      frac_of_f32_mfma_peak=round(samples_per_step * args.steps * FWD_BWD_FLOP_PER_SAMPLE / dt / 1e12 / world

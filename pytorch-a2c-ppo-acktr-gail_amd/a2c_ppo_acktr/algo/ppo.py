@@ -188,6 +188,9 @@ class PPO():
         rows = T * N
         dev = rollouts.rewards.device
         mbs = rows // self.num_mini_batch
+        # batches the sampler really yields (BatchSampler(drop_last=True), storage.py:122-125): more than
+        # num_mini_batch when rows is not a multiple of it (80 rows / 32 -> 40 batches of 2)
+        nb = rows // max(mbs, 1)
         lo, hi = self.dp.bounds(mbs)
         key = (rollouts.obs.data_ptr(), rollouts.actions.data_ptr(), rollouts.returns.data_ptr(),
                rollouts.value_preds.data_ptr(), rollouts.action_log_probs.data_ptr(), T, N, mbs, lo, hi,
@@ -226,10 +229,10 @@ class PPO():
             per_pos = graph_ok and (not self.dp.active or full)
             if graph_ok and self._graphs is None:           # capture (records only; executes nothing)
                 if per_pos:
-                    self._idx_all = torch.zeros(self.num_mini_batch, hi - lo, dtype=torch.int64, device=dev)
-                    g = torch.cuda.CUDAGraph()              # the whole epoch: num_mini_batch steps back to back
+                    self._idx_all = torch.zeros(nb, hi - lo, dtype=torch.int64, device=dev)
+                    g = torch.cuda.CUDAGraph()              # the whole epoch: nb steps back to back
                     with torch.cuda.graph(g):
-                        for k in range(self.num_mini_batch):
+                        for k in range(nb):
                             if self.dp.active:
                                 self._dp_step(dict(b, idx=self._idx_all[k]), split, None, capturing=True)
                             else:
@@ -251,15 +254,15 @@ class PPO():
                 self._graph_key = key
             self._seen_key = key
             for e in range(self.ppo_epoch):
-                batches = rollouts.minibatch_index_batches(self.num_mini_batch)         # ppo.py:48-51
                 if per_pos:
-                    batches = list(batches)                 # (one randperm per epoch either way: same RNG consumption)
-                    assert len(batches) == self.num_mini_batch
-                    self._idx_all.copy_(torch.stack([ind[lo:hi] for ind in batches]))
+                    # (one randperm per epoch either way: same RNG consumption); the batches are consecutive slices of
+                    # one device permutation, so the epoch's index table is a strided view of it
+                    perm, _, _ = rollouts.minibatch_permutation(self.num_mini_batch)    # ppo.py:48-51
+                    self._idx_all.copy_(perm[:nb * mbs].view(nb, mbs)[:, lo:hi])
                     self._graphs[0].replay()
-                    self.optimizer.step_count += self.num_mini_batch
+                    self.optimizer.step_count += nb
                     continue
-                for indices in batches:
+                for indices in rollouts.minibatch_index_batches(self.num_mini_batch):   # ppo.py:48-51
                     self._idx.copy_(indices[lo:hi])
                     if self.dp.active:
                         self._dp_step(b, split, self._graphs if graph_ok else None)

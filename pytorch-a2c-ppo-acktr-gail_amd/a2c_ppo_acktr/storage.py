@@ -144,10 +144,21 @@ class RolloutStorage(object):
                 "".format(num_processes, num_steps, num_processes * num_steps,
                           num_mini_batch))
             mini_batch_size = batch_size // num_mini_batch
+        perm_dev, mini_batch_size, nb = self.minibatch_permutation(num_mini_batch, mini_batch_size, _checked=True)
+        return (perm_dev[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(nb))
+
+    def minibatch_permutation(self, num_mini_batch=None, mini_batch_size=None, _checked=False):
+        """The permutation behind minibatch_index_batches as ONE int64 device tensor plus (mini_batch_size, number of
+        batches): batch i is perm[i*mbs:(i+1)*mbs], so an epoch's index table is perm[:nb*mbs].view(nb, mbs)."""
+        num_steps, num_processes = self.rewards.size()[0:2]
+        batch_size = num_processes * num_steps
+        if mini_batch_size is None:
+            if not _checked:
+                assert batch_size >= num_mini_batch
+            mini_batch_size = batch_size // num_mini_batch
         perm = torch.randperm(batch_size)
         perm_dev = perm.to(self.rewards.device, non_blocking=True)
-        nb = batch_size // mini_batch_size
-        return (perm_dev[i * mini_batch_size:(i + 1) * mini_batch_size] for i in range(nb))
+        return perm_dev, mini_batch_size, batch_size // mini_batch_size
 
     def feed_forward_generator(self, advantages, num_mini_batch=None, mini_batch_size=None):
         """reference storage.py:107-143: yields the same 8-tuples, gathered on the GPU."""

@@ -112,3 +112,69 @@ def test_eig_owner_assignment_balanced_and_deterministic():
         crit = max(float(s) ** 3 for s in sizes)
         assert max(loads) <= max(crit, sum(loads) / world) * 1.34 + 1    # LPT bound (4/3) against the 1568 factor
     assert assign_eig_owners(sizes, 8)[12] != assign_eig_owners(sizes, 8)[8]   # 1568 and 576 on different ranks
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# bench.py's own N-rank launcher (the driver may run `python bench.py --gpus N` without torch.distributed.run)
+# ---------------------------------------------------------------------------------------------------------------
+BENCH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'bench.py')
+
+
+def _run(cmd, env=None, timeout=240):
+    import subprocess
+    e = dict(os.environ)
+    for k in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize('world', [2, 4])
+def test_bench_self_launch_reaches_rendezvous(world):
+    """`python bench.py --gpus N` with no launcher environment starts N fresh ranks itself; `--launch-check` stops
+    before the first device call (gloo rendezvous + one all-reduce), so the launcher runs on a CPU box."""
+    import json
+    import sys
+    r = _run([sys.executable, BENCH, '--gpus', str(world), '--launch-check'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                       # stdout carries exactly one line, rank 0's
+    rec = json.loads(lines[0])
+    assert rec == dict(launch_check=True, world=world, backend='gloo', sum=world * (world + 1) / 2)
+
+
+def test_bench_under_torch_distributed_run():
+    """The driver's documented N > 1 form: python -m torch.distributed.run ... bench.py --gpus N."""
+    import json
+    import sys
+    r = _run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr',
+              '127.0.0.1', '--master-port', str(_free_port()), BENCH, '--gpus', '2', '--launch-check'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    rec = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert rec == [dict(launch_check=True, world=2, backend='gloo', sum=3.0)]
+
+
+def test_bench_gpus_beyond_device_count_fails_cleanly():
+    """More ranks than GPUs: a message naming the device count and exit code 2 before anything is started -- not an
+    AssertionError from inside a rank."""
+    import sys
+    n = torch.cuda.device_count() + 2
+    r = _run([sys.executable, BENCH, '--gpus', str(n)], timeout=120)
+    assert r.returncode == 2
+    assert 'needs %d GPUs' % n in r.stderr and 'exposes %d' % (n - 2) in r.stderr
+    assert 'AssertionError' not in r.stderr and r.stdout.strip() == ''
+    # and a launcher environment that disagrees with --gpus
+    r = _run([sys.executable, BENCH, '--gpus', '2'], env=dict(WORLD_SIZE='3', RANK='0', LOCAL_RANK='0'), timeout=120)
+    assert r.returncode == 2 and 'WORLD_SIZE=3' in r.stderr
+
+
+def test_bench_self_launch_propagates_rank_failure():
+    """A rank that dies takes the command down with a non-zero exit code (the other ranks are stopped, not left in
+    the rendezvous)."""
+    import sys
+    import time
+    t0 = time.time()
+    r = _run([sys.executable, BENCH, '--gpus', '2', '--launch-check'], env=dict(ACKTR_BENCH_TEST_FAIL_RANK='1'))
+    assert r.returncode != 0
+    assert 'rank 1 exited' in r.stderr
+    assert time.time() - t0 < 120

@@ -178,6 +178,48 @@ def test_ppo_deferred_head_finalize_matches_own_launch():
     np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=2e-7)
 
 
+@pytest.mark.parametrize('kind', ['mlp', 'cnn'])
+def test_ppo_rows_not_multiple_of_minibatches(kind):
+    """The reference's defaults (arguments.py: 5 steps x 16 processes, num_mini_batch 32): 80 rows give batches of 2 and
+    BatchSampler(drop_last=True) yields 40 of them per epoch, not 32 (storage.py:121-125).  The captured epoch graph must
+    run all 40; four updates on the graph path (replays from the second on) against the launch-by-launch path, and the
+    returned losses against the oracle's ppo_update for the first update (which divides by ppo_epoch * num_mini_batch like
+    ppo.py:90, whatever the batch count)."""
+    from a2c_ppo_acktr import algo
+    from oracle import algo_ref
+    T, N, A = 5, 16, 3
+    od = 11
+    hp = dict(clip_param=0.2, ppo_epoch=2, num_mini_batch=32, value_loss_coef=0.5, entropy_coef=0.01, lr=3e-4, eps=1e-5,
+              max_grad_norm=0.5)
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=741)
+    out = {}
+    for use_graph in (True, False):
+        pol = make_policy(kind, od, A, 63)
+        rs = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
+        rs.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
+        agent = algo.PPO(pol, **hp)
+        agent.use_graph = use_graph
+        losses = []
+        for it in range(4):
+            torch.manual_seed(1234 + it)
+            losses.append(agent.update(rs))
+        assert agent.optimizer.step_count == 4 * 2 * 40
+        out[use_graph] = (np.array(losses), pol.flat_params.detach().cpu().numpy().copy())
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=1e-5)
+    # the oracle on the same weights / rollouts / CPU seed
+    P = OrderedDict((k, t(v)) for k, v in synth.make_params(shapes_for(kind, od, A), 63).items())
+    roc = {k: t(v) for k, v in ro.items()}
+    rs0 = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
+    rs0.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
+    roc['returns'] = rs0.returns.cpu()
+    roc['value_preds'] = rs0.value_preds.cpu()
+    torch.manual_seed(1234)
+    ref = algo_ref.ppo_update(P, algo_ref.adam_init(P), roc, **hp)
+    np.testing.assert_allclose(out[True][0][0], np.array(ref), rtol=2e-4, atol=1e-6)
+
+
 @pytest.mark.parametrize('ci', range(len(A2C_CASES)))
 def test_a2c_update_vs_reference(ci):
     """Losses: 1e-4 vs the reference golden on every update.  Parameters: 1e-4 after the first update.

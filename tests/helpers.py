@@ -191,6 +191,23 @@ def update_vector_errors(G, prefix_fmt, names, get_mine, get_truth):
     return np.sqrt(e_ref / nt), np.sqrt(e_mine / nt), np.sqrt(e_mg / nt)
 
 
+def reference_self_distance(prefix_fmt, names, other='kfac_t8', base='kfac', other_prefix_fmt=None):
+    """|| ref(1 thread) - ref(8 threads) || / || ref(1 thread) || over the whole vector made of the tensors `names`
+    (estimated on the goldens' stored subsets like update_vector_errors): how far the REFERENCE moves against itself
+    when only the intra-op thread count of its CPU run changes (tests/golden/make_golden_kfac.py --threads 8 against
+    the committed 1-thread goldens, main.py:38)."""
+    G1, G8 = golden(base), golden(other)
+    num = den = 0.0
+    for n in names:
+        key = prefix_fmt % n
+        suf = '#full' if key + '#full' in G1.files else '#sample'
+        a, b = G1[key + suf].astype(np.float64), G8[(other_prefix_fmt or prefix_fmt) % n + suf].astype(np.float64)
+        frac = a.size / (a.size if suf == '#full' else a.size * float(SAMPLE_STRIDE))
+        num += np.sum((a - b) ** 2) / frac
+        den += np.sum(a ** 2) / frac
+    return float(np.sqrt(num / max(den, 1e-300)))
+
+
 # ------------------------------------------------------------------------------------------ GAIL (SURVEY 8(f) rank 1-2)
 GAIL_CASES = [('hc', 17, 6, 100, 128, 8, 64), ('small', 11, 3, 64, 32, 5, 16)]     # tag, obs, act, hidden, batch, T, N
 

@@ -7,7 +7,8 @@ import pytest
 import torch
 
 import synth
-from helpers import KFAC_CASES, check_summary, golden, kfac_golden, t, unsplit_name, update_vector_errors
+from helpers import (KFAC_CASES, check_summary, golden, kfac_golden, reference_self_distance, t, unsplit_name,
+                     update_vector_errors)
 from oracle import kfac_ref
 from test_policy_gpu import Box, Discrete, make_policy, make_storage
 
@@ -323,8 +324,22 @@ def test_acktr_update_vs_reference(ci):
                                               lambda n: truth[it][unsplit_name(n)])
             print('    %-36s ref %.2e mine %.2e norm %.3g' % (n, r1, r2, float(G[tag + '/update%d/kfgrad/%s#norm' % (it, n)])))
         assert e_mine <= 1.0 * e_ref + 1e-3, (it, e_ref, e_mine, e_mg)
-        if kind == 'mlp':      # every factor full rank here: the direct north-star bar holds
-            assert e_mg <= 1e-3, (it, e_mg)
+        # Directly against the reference golden (north_star: 1e-3 relative).  How well the reference pins its OWN answer
+        # is a committed fixture: the same reference code run with 8 intra-op threads instead of 1 (tests/golden/
+        # kfac_t8.npz; self-distances recorded in tests/test_oracle_kfac.py::test_reference_self_distance) and the
+        # fp64 run of the same algorithm.  Where both agree with the golden to 1e-3 (MLP: every factor full rank) the
+        # bar is 1e-3; elsewhere it is the reference's own uncertainty + 1e-3 (an EXACT solver sits at e_ref from the
+        # golden, so no implementation can do better than that).
+        if tag.endswith('_fast'):
+            self_d = None                      # no 8-thread fixture for the fast_cnn variant: fp64 anchor only
+            unc = e_ref
+        else:
+            self_d = reference_self_distance(tag + '/update%d/kfgrad/' % it + '%s', names)
+            unc = max(self_d, e_ref)
+        bar = 1e-3 if unc <= 1e-3 else unc + 1e-3
+        print(tag, 'update', it, 'ours-vs-golden %.3g  bar %.3g  (reference 1-vs-8 threads %s, reference-vs-fp64 %.3g, '
+              'ours-vs-fp64 %.3g)' % (e_mg, bar, 'n/a' if self_d is None else '%.3g' % self_d, e_ref, e_mine))
+        assert e_mg <= bar, (it, e_mg, bar, self_d, e_ref, e_mine)
         p_ref, p_mine, p_mg = update_vector_errors(G, tag + '/update%d/param/' % it + '%s', names,
                                                    lambda n: params[n].detach().cpu().numpy(),
                                                    lambda n: truth[it]['param:' + unsplit_name(n)])

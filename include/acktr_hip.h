@@ -214,9 +214,10 @@ typedef struct acktr_head_fin {
 int acktr_head_step_deferred_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh,
                                  float* dfeat, float* dwh, float* dbh, int H, acktr_head_fin* pending, void* stream);
 
-/* dist.log_probs(action) and dist.entropy() per sample -- model.py:74-77 (entropy.mean() is taken by the host). */
+/* dist.log_probs(action) and dist.entropy() per sample -- model.py:74-77; entropy_mean (nullable, one float) receives
+ * dist.entropy().mean() of model.py:77 (fixed summation order). */
 int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions, int B, int A,
-                       float* logp, float* entropy, void* stream);
+                       float* logp, float* entropy, float* entropy_mean, void* stream);
 /* Rollout-side head of Policy.act -- model.py:54-66, distributions.py:22-25,28-29,37-44: the mode (deterministic != 0)
  * or one sample per row, and dist.log_probs(action) of it.  Categorical: action_out int64[B]; sampling = inverse CDF of
  * softmax(logits) at the caller's uniform noise[B] in [0,1) (the reference draws with torch.multinomial on its own
@@ -225,10 +226,12 @@ int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* log
 int acktr_dist_act_f32(int dist, const float* dist_in, long ld, const float* logstd, const float* noise,
                        int deterministic, int B, int A, void* action_out, float* logp, void* stream);
 /* their backward: ddist = dlogp[b]*dlogp/d(dist_in) + dentropy[b]*dentropy/d(dist_in) (either seed nullable);
- * gaussian also returns dlogstd[A] (workspace >= acktr_policy_loss_workspace_bytes(B, A)). */
+ * gaussian also returns dlogstd[A] (workspace >= acktr_policy_loss_workspace_bytes(B, A)) and, if dlogstd_rows is not
+ * null, its per-row terms [B,A]: the grad_output of the logstd AddBias module that KFAC's backward hook reads
+ * (algo/kfac.py:161-177 through distributions.py:90-95). */
 int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions,
                        const float* dlogp, const float* dentropy, int B, int A, float* ddist, long ldd, float* dlogstd,
-                       void* workspace, long workspace_bytes, void* stream);
+                       float* dlogstd_rows, void* workspace, long workspace_bytes, void* stream);
 
 /* ---- optimisers on flat parameter buffers ------------------------------------------------- */
 

@@ -117,9 +117,9 @@ _PROTOS = {
     'acktr_head_step_f32': (c_i, [ctypes.POINTER(LossArgs), c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),
     'acktr_head_step_deferred_f32': (c_i, [ctypes.POINTER(LossArgs), c_p, c_p, c_p, c_p, c_p, c_p, c_i,
                                            ctypes.POINTER(HeadFin), c_p]),
-    'acktr_dist_fwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p]),
+    'acktr_dist_fwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     'acktr_dist_act_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_i, c_i, c_i, c_p, c_p, c_p]),
-    'acktr_dist_bwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p, c_p, c_l, c_p]),
+    'acktr_dist_bwd_f32': (c_i, [c_i, c_p, c_l, c_p, c_p, c_p, c_p, c_i, c_i, c_p, c_l, c_p, c_p, c_p, c_l, c_p]),
     'acktr_optim_workspace_bytes': (c_l, []),
     'acktr_clip_adam_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_clip_adam_dev_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p]),

@@ -107,6 +107,8 @@ class KFACOptimizer(optim.Optimizer):
         self._ext_noise = None
         self._side_stream = None
         self._bcast_buf = None
+        self._n_stats = {'a': 0, 'g': 0}       # running-average updates so far (step() refuses to run on none)
+        engine.register_kfac(model, self)
 
     # ------------------------------------------------------------------ module discovery (kfac.py:179-188)
     def _prepare_model(self):
@@ -151,6 +153,7 @@ class KFACOptimizer(optim.Optimizer):
             da += al4(m.na)
             dg += al4(m.ng)
         z = lambda n: torch.zeros(n, dtype=f32, device=dev)
+        self._bias_a_done = set()       # (the AddBias slots of the NEW sample bucket have not been filled)
         self.aa_sample, self.gg_sample = z(oa), z(og)
         self.aa_run, self.gg_run = z(oa), z(og)
         self.qt_a, self.qt_g = z(oa), z(og)
@@ -238,12 +241,75 @@ class KFACOptimizer(optim.Optimizer):
         cnn = acts.cnn
         dev = acts.head.device if cnn else acts.v.device
         self._setup(dev)
-        L = _hip.lib()
         B = acts.head.shape[0] if cnn else acts.v.shape[0]       # local rows
         Bg = int(round(1.0 / inv_batch))                         # global batch (kfac.py:30,50 use the full batch)
+        self._stats_a(acts, B, Bg)
+
+        # ---- sampled Fisher loss and its data-gradient chain (a2c_acktr.py:56-68)
+        rows_total = Bg
+        if self._ext_noise is not None:                           # hipGraph capture: the caller refills this buffer
+            noise = self._ext_noise.view(-1)                      # from the same CPU draw before every replay
+        else:
+            noise = torch.randn(rows_total, 1)                    # CPU default generator, like the reference (F7)
+            noise = noise.to(dev, non_blocking=True).view(-1)
+        dls_rows = None
+        if pol.dist.kind == 1:
+            dls_rows = torch.empty(B, pol.dist.num_outputs, dtype=f32, device=dev)
+        scratch_g = self.v_flat                                   # d logstd sum lands here; overwritten in step()
+        engine.policy_loss(pol, acts, engine.ALGO_FISHER, actions, None, inv_batch, adv=noise, gather_idx=gather_idx,
+                           gflat=scratch_g, dlogstd_rows=dls_rows)
+        engine.backward(pol, acts, scratch_g, keep=True, wgrad=False)
+        self._stats_g(acts, B, Bg, dls_rows)
+
+        # ---- data-parallel: SUM the sample factors (global scalings already applied), then running averages
+        dp.all_reduce_sum_many_((self.aa_sample, self.gg_sample))
+        self._running_stat('a')
+        self._running_stat('g')
+
+    # -- the reference's own call pattern (a2c_acktr.py:53-78 driven by user code): Policy.evaluate_actions and the
+    # -- backward of its autograd node call these where the module hooks of kfac.py:144-177 fire
+    def on_forward(self, acts):
+        """kfac.py:144-159 (_save_input, a forward-pre hook on every known module): with grad enabled and
+        steps % Ts == 0, EVERY forward updates the running input statistics m_aa."""
+        cnn = acts.cnn
+        dev = acts.head.device if cnn else acts.v.device
+        self._setup(dev)
+        B = acts.head.shape[0] if cnn else acts.v.shape[0]
+        with torch.no_grad():
+            self._stats_a(acts, B, B * self.dp.world)
+            self.dp.all_reduce_sum_(self.aa_sample)
+            self._running_stat('a')
+
+    def on_backward(self, acts, dls_rows):
+        """kfac.py:161-177 (_save_grad_output, a backward hook): while `acc_stats` is set (and steps % Ts == 0) a
+        backward pass updates the running grad-output statistics m_gg.  `acts` carries the pre-activation gradients of
+        that pass (engine.backward(keep=True)), dls_rows the logstd module's grad_output (Gaussian heads)."""
+        cnn = acts.cnn
+        B = acts.head.shape[0] if cnn else acts.v.shape[0]
+        with torch.no_grad():
+            self._stats_g(acts, B, B * self.dp.world, dls_rows)
+            self.dp.all_reduce_sum_(self.gg_sample)
+            self._running_stat('g')
+
+    def _running_stat(self, which):
+        """update_running_stat (kfac.py:67-71) over one flat bucket; the first update of a bucket initialises the
+        running average to the sample (kfac.py:156-157,174-175: `steps == 0` clones)."""
+        run, smp = (self.aa_run, self.aa_sample) if which == 'a' else (self.gg_run, self.gg_sample)
+        init = 1 if self.steps == 0 else 0
+        d = float(self.stat_decay)
+        rc = _hip.lib().acktr_kfac_running_stat_f32(_hip.dev_ptr(run), _hip.dev_ptr(smp), run.numel(), d / (1 - d), 1 - d,
+                                                    init, _hip.cur_stream(run.device))
+        _hip.check(rc, 'acktr_kfac_running_stat_f32')
+        self._n_stats[which] += 1
+
+    def _stats_a(self, acts, B, Bg):
+        """compute_cov_a of every known module into the sample bucket (kfac.py:29-46)."""
+        pol = self.model
+        cnn = acts.cnn
+        dev = self.aa_sample.device
+        L = _hip.lib()
         stream = _hip.cur_stream(dev)
         view_a = lambda m: self.aa_sample[m.oa:m.oa + m.na * m.na]
-        view_g = lambda m: self.gg_sample[m.og:m.og + m.ng * m.ng]
 
         # ---- A factors: compute_cov_a on the layer inputs (kfac.py:29-46)
         if cnn:
@@ -288,22 +354,16 @@ class KFACOptimizer(optim.Optimizer):
                 a = lin_in[m.layer]
                 self._cov_dense(a, a.data_ptr(), a.shape[1], B, a.shape[1], 1.0 / Bg, out)
 
-        # ---- sampled Fisher loss and its data-gradient chain (a2c_acktr.py:56-68)
-        rows_total = Bg
-        if self._ext_noise is not None:                           # hipGraph capture: the caller refills this buffer
-            noise = self._ext_noise.view(-1)                      # from the same CPU draw before every replay
-        else:
-            noise = torch.randn(rows_total, 1)                    # CPU default generator, like the reference (F7)
-            noise = noise.to(dev, non_blocking=True).view(-1)
-        dls_rows = None
-        gauss = pol.dist.kind == 1
-        if gauss:
-            dls_rows = torch.empty(B, pol.dist.num_outputs, dtype=f32, device=dev)
-        scratch_g = self.v_flat                                   # d logstd sum lands here; overwritten in step()
-        engine.policy_loss(pol, acts, engine.ALGO_FISHER, actions, None, inv_batch, adv=noise, gather_idx=gather_idx,
-                           gflat=scratch_g, dlogstd_rows=dls_rows)
-        engine.backward(pol, acts, scratch_g, keep=True, wgrad=False)
 
+    def _stats_g(self, acts, B, Bg, dls_rows):
+        """compute_cov_g of every known module into the sample bucket (kfac.py:49-64)."""
+        pol = self.model
+        cnn = acts.cnn
+        dev = self.gg_sample.device
+        L = _hip.lib()
+        stream = _hip.cur_stream(dev)
+        gauss = pol.dist.kind == 1
+        view_g = lambda m: self.gg_sample[m.og:m.og + m.ng * m.ng]
         # ---- G factors: compute_cov_g on the grad_outputs (kfac.py:49-64)
         if cnn:
             conv_g = {'conv1': acts.dy1, 'conv2': acts.dy2, 'conv3': acts.dy3}
@@ -341,15 +401,6 @@ class KFACOptimizer(optim.Optimizer):
             else:
                 ptr, ld, D = lin_g[m.layer]
                 self._cov_dense(None, ptr, ld, B, D, float(Bg), out)
-
-        # ---- data-parallel: SUM the sample factors (global scalings already applied), then running averages
-        dp.all_reduce_sum_many_((self.aa_sample, self.gg_sample))
-        init = 1 if self.steps == 0 else 0
-        for run, smp in ((self.aa_run, self.aa_sample), (self.gg_run, self.gg_sample)):
-            d = float(self.stat_decay)
-            rc = L.acktr_kfac_running_stat_f32(_hip.dev_ptr(run), _hip.dev_ptr(smp), run.numel(), d / (1 - d), 1 - d,
-                                               init, stream)
-            _hip.check(rc, 'acktr_kfac_running_stat_f32')
 
     # ------------------------------------------------------------------ eigendecompositions (kfac.py:205-214)
     def _eigendecompose(self):
@@ -392,6 +443,12 @@ class KFACOptimizer(optim.Optimizer):
             if big_thread is not None:
                 big_thread.join()
             _hip.check(rc, 'acktr_sym_eig_jacobi_block_f32')
+            # a factor that has not met the rotation criterion after the sweep limit is reported through a negative sweep
+            # count, not through rc: the reference's symeig converges or raises, so such a factor is solved again by
+            # rocSOLVER instead of passing a half-rotated basis to the preconditioner
+            bad = [w for w, sw in zip(self._blk, self._blk_sweeps) if sw < 0]
+            if bad:
+                self._solve_rocsolver(bad)
         if big_err:
             raise RuntimeError('acktr_sym_eig_rocsolver_multi_f32 failed (rc=%d): %s' % big_err[0])
         if side is not None:
@@ -421,6 +478,22 @@ class KFACOptimizer(optim.Optimizer):
                         t_.copy_(buf[o:o + t_.numel()])
                         o += t_.numel()
 
+    def _solve_rocsolver(self, work):
+        """syevd on the listed (run, qt, d, off, doff, n) factors on the current stream (fallback path)."""
+        L = _hip.lib()
+        dev = self.aa_run.device
+        for run, qt, dfl, off, doff, n in work:
+            qt[off:off + n * n].copy_(run[off:off + n * n])
+        jobs = (_hip.EigJob * len(work))(*[_hip.EigJob(qt.data_ptr() + 4 * off, dfl.data_ptr() + 4 * doff, n, 0)
+                                           for run, qt, dfl, off, doff, n in work])
+        e_work = torch.zeros(sum(w[5] for w in work), dtype=f32, device=dev)
+        info = torch.zeros(len(work), dtype=torch.int32, device=dev)
+        rc = L.acktr_sym_eig_rocsolver_multi_f32(jobs, len(work), _hip.dev_ptr(e_work), _hip.dev_ptr(info, torch.int32),
+                                                 1e-6, _hip.cur_stream(dev))
+        _hip.check(rc, 'acktr_sym_eig_rocsolver_multi_f32')
+        if int(info.abs().sum().item()) != 0:
+            raise RuntimeError('KFAC eigendecomposition did not converge (blocked Jacobi and rocSOLVER syevd both failed)')
+
     def _precond_jobs(self, pol, gflat):
         """ctypes job table of the batched preconditioner: per layer its gradient slot, eigenbases / eigenvalues, the slot
         of the update vector, and two scratch slots of the same size (flat buffers laid out like the parameters)."""
@@ -449,9 +522,16 @@ class KFACOptimizer(optim.Optimizer):
         L = _hip.lib()
         stream = _hip.cur_stream(dev)
         with torch.no_grad():
+            pol.adopt_grads()
             if self.weight_decay > 0:
                 gflat.add_(flat, alpha=self.weight_decay)         # kfac.py:192-194 (never enabled by the reference driver)
             la = self.damping + self.weight_decay
+            if self._n_stats['a'] == 0 or self._n_stats['g'] == 0:
+                # the reference fails here too (KeyError on the empty m_aa / m_gg dicts, kfac.py:205-214)
+                raise RuntimeError('KFACOptimizer.step(): no Kronecker-factor statistics have been accumulated (m_aa: %d, '
+                                   'm_gg: %d updates).  Drive it like a2c_acktr.py:53-78: evaluate_actions() with grad '
+                                   'enabled, then `acc_stats = True; fisher_loss.backward(retain_graph=True); acc_stats = '
+                                   'False` -- or call A2C_ACKTR.update().' % (self._n_stats['a'], self._n_stats['g']))
             if self.steps % self.Tf == 0:
                 self._eigendecompose()
                 # Q next to Q^T: with both, every operand of the four preconditioner products is contiguous along its output
@@ -483,4 +563,7 @@ class KFACOptimizer(optim.Optimizer):
         self.steps += 1
 
     def zero_grad(self, set_to_none=False):
+        """optimizer.zero_grad() of a2c_acktr.py:70: afterwards every p.grad is a zeroed view of the flat gradient bucket,
+        so the backward() that follows accumulates straight into what step() reads."""
         self.model.flat_grads.zero_()
+        self.model.bind_grads()

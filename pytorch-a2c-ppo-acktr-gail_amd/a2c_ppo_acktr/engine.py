@@ -547,10 +547,32 @@ def mlp_fused_step(policy, obs, gather_idx, B, algo, actions, loss_acc, inv_batc
 # ----------------------------------------------------------------------------------------------
 # autograd bridge for Policy.evaluate_actions (model.py:72-79)
 # ----------------------------------------------------------------------------------------------
+_KFAC_OF = None        # policy -> weakref of the KFACOptimizer built on it (its hooks' stand-in, algo/kfac.py)
+
+
+def register_kfac(policy, opt):
+    global _KFAC_OF
+    import weakref
+    if _KFAC_OF is None:
+        _KFAC_OF = weakref.WeakKeyDictionary()
+    _KFAC_OF[policy] = weakref.ref(opt)
+
+
+def kfac_of(policy):
+    r = _KFAC_OF.get(policy) if _KFAC_OF is not None else None
+    return r() if r is not None else None
+
+
 class EvalActions(torch.autograd.Function):
+    """`kfac`: the KFACOptimizer whose module hooks (kfac.py:144-188) this node stands in for, or None.  `stats_a`: the
+    forward-pre hooks' condition (grad enabled and steps % Ts == 0, kfac.py:145) as evaluated by the caller -- grad mode
+    is off inside an autograd.Function's forward."""
+
     @staticmethod
-    def forward(ctx, policy, inputs, action, rnn_hxs, masks, *params):
+    def forward(ctx, policy, inputs, action, rnn_hxs, masks, kfac, stats_a, *params):
         acts = forward(policy, inputs, rnn_hxs=rnn_hxs, masks=masks)
+        if kfac is not None and stats_a:
+            kfac.on_forward(acts)
         B = inputs.shape[0]
         A = policy.dist.num_outputs
         dev = inputs.device
@@ -565,14 +587,15 @@ class EvalActions(torch.autograd.Function):
             act = act.to(f32)
         ls = logstd_param(policy).detach() if kind == 1 else None
         dp, dld = acts.dist_ptr_ld()
+        ent_mean = torch.empty((), dtype=f32, device=dev)
         rc = L.acktr_dist_fwd_f32(kind, dp, dld, _hip.dev_ptr(ls), _hip.dev_ptr(act), B, A, _hip.dev_ptr(logp),
-                                  _hip.dev_ptr(ent), _hip.cur_stream(dev))
+                                  _hip.dev_ptr(ent), _hip.dev_ptr(ent_mean), _hip.cur_stream(dev))
         _hip.check(rc, 'acktr_dist_fwd_f32')
-        ctx.policy, ctx.acts, ctx.act = policy, acts, act
+        ctx.policy, ctx.acts, ctx.act, ctx.kfac = policy, acts, act, kfac
         ctx.nparams = len(params)
         hxs_out = acts.hxs_out.clone() if policy.is_recurrent else torch.zeros(1, device=dev)
         ctx.mark_non_differentiable(hxs_out)
-        return acts.value().clone(), logp, ent.mean(), hxs_out
+        return acts.value().clone(), logp, ent_mean, hxs_out
 
     @staticmethod
     def backward(ctx, dvalue, dlogp, dent, _dhxs):
@@ -594,12 +617,18 @@ class EvalActions(torch.autograd.Function):
         ls = logstd_param(policy) if kind == 1 else None
         ws = ops.workspace(dev, L.acktr_policy_loss_workspace_bytes(B, A), 'loss')
         dp, dld = acts.dist_ptr_ld()
+        # KFAC's backward hooks fire while `acc_stats` is set, at steps % Ts == 0 (kfac.py:161-164)
+        kfac = ctx.kfac
+        stats_g = kfac is not None and kfac.acc_stats and kfac.steps % kfac.Ts == 0
+        dls_rows = torch.empty(B, A, dtype=f32, device=dev) if (stats_g and kind == 1) else None
         rc = L.acktr_dist_bwd_f32(kind, dp, dld, _hip.dev_ptr(ls.detach() if ls is not None else None),
                                   _hip.dev_ptr(act), _hip.dev_ptr(dl), _hip.dev_ptr(de), B, A, ddp, ddld,
                                   _hip.dev_ptr(policy.grad_view(ls, gflat) if ls is not None else None),
-                                  _hip.dev_ptr(ws), ws.numel(), _hip.cur_stream(dev))
+                                  _hip.dev_ptr(dls_rows), _hip.dev_ptr(ws), ws.numel(), _hip.cur_stream(dev))
         _hip.check(rc, 'acktr_dist_bwd_f32')
-        backward(policy, acts, gflat)
+        backward(policy, acts, gflat, keep=stats_g)
+        if stats_g:
+            kfac.on_backward(acts, dls_rows)
         grads = tuple(policy.grad_view(p, gflat) for p in policy.parameters())
         assert len(grads) == ctx.nparams
-        return (None, None, None, None, None) + grads
+        return (None, None, None, None, None, None, None) + grads

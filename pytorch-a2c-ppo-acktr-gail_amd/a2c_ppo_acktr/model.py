@@ -146,6 +146,16 @@ class Policy(nn.Module):
             if p.grad is None or p.grad.data_ptr() != gv.data_ptr():
                 p.grad = gv
 
+    def adopt_grads(self):
+        """Gradients that autograd left in tensors of their own (after `module.zero_grad()` set .grad to None, the next
+        backward() allocates fresh ones) are copied into the flat gradient bucket and re-bound, so an optimiser of this
+        package that is driven by user code (loss.backward(); optimizer.step()) steps on them."""
+        for p in self.parameters():
+            gv = self.grad_view(p)
+            if p.grad is not None and p.grad.data_ptr() != gv.data_ptr():
+                gv.copy_(p.grad)
+                p.grad = gv
+
     # ------------------------------------------------------------------ reference API
     @property
     def is_recurrent(self):
@@ -202,10 +212,15 @@ class Policy(nn.Module):
         Differentiable w.r.t. every parameter through a torch.autograd.Function whose forward and
         backward are the HIP kernels."""
         if self.is_recurrent:
-            value, logp, ent, hxs = engine.EvalActions.apply(self, inputs, action, rnn_hxs, masks,
+            value, logp, ent, hxs = engine.EvalActions.apply(self, inputs, action, rnn_hxs, masks, None, False,
                                                              *list(self.parameters()))
             return value, logp, ent, hxs
-        value, logp, ent, _ = engine.EvalActions.apply(self, inputs, action, None, None, *list(self.parameters()))
+        # a KFACOptimizer built on this policy gathers its statistics here, where the reference's module hooks fire
+        # (kfac.py:144-177): input statistics on every forward with grad enabled at steps % Ts == 0
+        kfac = engine.kfac_of(self)
+        stats_a = kfac is not None and torch.is_grad_enabled() and kfac.steps % kfac.Ts == 0
+        value, logp, ent, _ = engine.EvalActions.apply(self, inputs, action, None, None, kfac, stats_a,
+                                                       *list(self.parameters()))
         return value, logp, ent, rnn_hxs
 
 

@@ -121,6 +121,15 @@ __global__ __launch_bounds__(LOSS_THREADS) void dist_fwd_kernel(const float* dis
     entropy[b] = d.ent;
 }
 
+// entropy.mean() of model.py:77 -- one workgroup, fixed summation order (run-to-run deterministic)
+__global__ __launch_bounds__(LOSS_THREADS) void mean_kernel(const float* x, int n, float* out) {
+    __shared__ float sm[16];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += LOSS_THREADS) s += x[i];
+    const float r = block_sum(s, sm);
+    if (threadIdx.x == 0) out[0] = r / (float)n;
+}
+
 // Rollout-side head (Policy.act, model.py:54-66): mode or a sample of the action distribution and the log-prob of
 // the chosen action, one sample per lane.
 //   categorical: mode = first argmax of the logits (torch.argmax); sample = inverse CDF of softmax(logits) at the
@@ -171,7 +180,7 @@ template <int DIST>
 __global__ __launch_bounds__(LOSS_THREADS) void dist_bwd_kernel(const float* dist_in, long ld, const float* logstd,
                                                                 const void* actions, const float* dlogp,
                                                                 const float* dent, int B, int A, float* ddist, long ldd,
-                                                                float* partial) {
+                                                                float* partial, float* dls_rows) {
     __shared__ float sm[16];
     const int b = blockIdx.x * LOSS_THREADS + threadIdx.x;
     float dls[DIST == 1 ? 16 : 1];
@@ -192,6 +201,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void dist_bwd_kernel(const float* dis
                 const float var = sd * sd, dj = act[j] - din[j];
                 dd[j] = gl * dj / var;
                 dls[j] = gl * (dj * dj / var - 1.f) + ge;
+                if (dls_rows) dls_rows[(long)b * A + j] = dls[j];
             }
         }
     }
@@ -248,7 +258,7 @@ extern "C" int acktr_policy_loss_f32(const acktr_loss_args* args, void* stream) 
 }
 
 extern "C" int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions,
-                                  int B, int A, float* logp, float* entropy, void* stream) {
+                                  int B, int A, float* logp, float* entropy, float* entropy_mean, void* stream) {
     ACKTR_ARG(dist_in && actions && logp && entropy, "dist_fwd: null pointer");
     ACKTR_ARG(B > 0 && A > 0 && ld >= A, "dist_fwd: bad sizes");
     ACKTR_ARG(dist == 0 || (dist == 1 && logstd && A <= 16), "dist_fwd: bad distribution arguments");
@@ -261,6 +271,10 @@ extern "C" int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const
         hipLaunchKernelGGL((dist_fwd_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, B, A,
                            logp, entropy);
     ACKTR_LAUNCH_CHECK();
+    if (entropy_mean) {
+        hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(LOSS_THREADS), 0, s, entropy, B, entropy_mean);
+        ACKTR_LAUNCH_CHECK();
+    }
     return 0;
 }
 
@@ -284,7 +298,7 @@ extern "C" int acktr_dist_act_f32(int dist, const float* dist_in, long ld, const
 
 extern "C" int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions,
                                   const float* dlogp, const float* dentropy, int B, int A, float* ddist, long ldd,
-                                  float* dlogstd, void* workspace, long workspace_bytes, void* stream) {
+                                  float* dlogstd, float* dlogstd_rows, void* workspace, long workspace_bytes, void* stream) {
     ACKTR_ARG(dist_in && actions && ddist, "dist_bwd: null pointer");
     ACKTR_ARG(B > 0 && A > 0 && ld >= A && ldd >= A, "dist_bwd: bad sizes");
     ACKTR_ARG(dist == 0 || (dist == 1 && logstd && dlogstd && A <= 16), "dist_bwd: bad distribution arguments");
@@ -294,11 +308,11 @@ extern "C" int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const
     const int nblk = cdiv(B, LOSS_THREADS);
     if (dist == 0) {
         hipLaunchKernelGGL((dist_bwd_kernel<0>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, dlogp,
-                           dentropy, B, A, ddist, ldd, (float*)workspace);
+                           dentropy, B, A, ddist, ldd, (float*)workspace, (float*)nullptr);
         ACKTR_LAUNCH_CHECK();
     } else {
         hipLaunchKernelGGL((dist_bwd_kernel<1>), dim3(nblk), dim3(LOSS_THREADS), 0, s, dist_in, ld, logstd, actions, dlogp,
-                           dentropy, B, A, ddist, ldd, (float*)workspace);
+                           dentropy, B, A, ddist, ldd, (float*)workspace, dlogstd_rows);
         ACKTR_LAUNCH_CHECK();
         hipLaunchKernelGGL(policy_loss_finalize_kernel, dim3(1), dim3(64), 0, s, (const float*)workspace, nblk, 3 + A, 0.f,
                            (float*)nullptr, dlogstd);

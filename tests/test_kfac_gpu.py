@@ -327,7 +327,7 @@ def test_acktr_update_vs_reference(ci):
         # Directly against the reference golden (north_star: 1e-3 relative).  How well the reference pins its OWN answer
         # is a committed fixture: the same reference code run with 8 intra-op threads instead of 1 (tests/golden/
         # kfac_t8.npz; self-distances recorded in tests/test_oracle_kfac.py::test_reference_self_distance) and the
-        # fp64 run of the same algorithm.  Where both agree with the golden to 1e-3 (MLP: every factor full rank) the
+        # fp64 run of the same algorithm.  Where both agree with the golden to 5e-4 (MLP: every factor full rank) the
         # bar is 1e-3; elsewhere it is the reference's own uncertainty + 1e-3 (an EXACT solver sits at e_ref from the
         # golden, so no implementation can do better than that).
         if tag.endswith('_fast'):
@@ -336,7 +336,7 @@ def test_acktr_update_vs_reference(ci):
         else:
             self_d = reference_self_distance(tag + '/update%d/kfgrad/' % it + '%s', names)
             unc = max(self_d, e_ref)
-        bar = 1e-3 if unc <= 1e-3 else unc + 1e-3
+        bar = 1e-3 if unc <= 5e-4 else unc + 1e-3        # (pinned to half the tolerance, or not)
         print(tag, 'update', it, 'ours-vs-golden %.3g  bar %.3g  (reference 1-vs-8 threads %s, reference-vs-fp64 %.3g, '
               'ours-vs-fp64 %.3g)' % (e_mg, bar, 'n/a' if self_d is None else '%.3g' % self_d, e_ref, e_mine))
         assert e_mg <= bar, (it, e_mg, bar, self_d, e_ref, e_mine)
@@ -373,3 +373,66 @@ def test_acktr_graph_replay_matches_eager(ci):
     np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-5, atol=1e-7)
     err = np.linalg.norm(out[1][1] - out[0][1]) / np.linalg.norm(out[0][1])
     assert err < 1e-6, err
+
+
+@pytest.mark.parametrize('ci', [0, 1])
+def test_kfac_reference_call_pattern(ci):
+    """KFACOptimizer driven the way the reference drives it -- the body of a2c_acktr.py:33-80 written out as user code over
+    the drop-in API: evaluate_actions (forward-pre hooks -> m_aa), `acc_stats = True; fisher_loss.backward(retain_graph=
+    True)` (backward hooks -> m_gg), the real loss's backward, optimizer.step().  Factors, losses and parameters against
+    the reference goldens, like test_acktr_update_vs_reference; and step() without statistics must raise."""
+    from a2c_ppo_acktr.algo.kfac import KFACOptimizer
+    tag, kind, od, A, T, N = KFAC_CASES[ci]
+    G = kfac_golden(tag)
+    pol = make_policy(kind, od, A, 90 + ci)
+    obs_shape = (4, 84, 84) if kind == 'cnn' else (od,)
+    ro = synth.make_rollouts(T, N, obs_shape, 'discrete' if kind == 'cnn' else 'box', A, salt=820 + ci)
+    rs = make_storage(ro, obs_shape, Discrete(A) if kind == 'cnn' else Box(A))
+    rs.compute_returns(t(ro['next_value']).cuda(), False, 0.99, 0.95, False)
+    optimizer = KFACOptimizer(pol)
+    optimizer.Tf = 2
+    with pytest.raises(RuntimeError, match='no Kronecker-factor statistics'):
+        optimizer.step()
+    assert optimizer.steps == 0
+    names = [str(n) for n in G[tag + '/param_names']]
+    params = dict(pol.named_parameters())
+    value_loss_coef, entropy_coef = 0.5, 0.01
+    for it in range(3):
+        torch.manual_seed(555 + it)
+        # ---- a2c_acktr.py:34-51
+        num_steps, num_processes, _ = rs.rewards.size()
+        values, action_log_probs, dist_entropy, _ = pol.evaluate_actions(
+            rs.obs[:-1].view(-1, *obs_shape), rs.recurrent_hidden_states[0].view(-1, 1), rs.masks[:-1].view(-1, 1),
+            rs.actions.view(-1, rs.actions.size(-1)))
+        values = values.view(num_steps, num_processes, 1)
+        action_log_probs = action_log_probs.view(num_steps, num_processes, 1)
+        advantages = rs.returns[:-1] - values
+        value_loss = advantages.pow(2).mean()
+        action_loss = -(advantages.detach() * action_log_probs).mean()
+        # ---- a2c_acktr.py:53-68
+        if optimizer.steps % optimizer.Ts == 0:
+            pol.zero_grad()
+            pg_fisher_loss = -action_log_probs.mean()
+            value_noise = torch.randn(values.size()).cuda()
+            sample_values = values + value_noise
+            vf_fisher_loss = -(values - sample_values.detach()).pow(2).mean()
+            fisher_loss = pg_fisher_loss + vf_fisher_loss
+            optimizer.acc_stats = True
+            fisher_loss.backward(retain_graph=True)
+            optimizer.acc_stats = False
+        # ---- a2c_acktr.py:70-80
+        optimizer.zero_grad()
+        (value_loss * value_loss_coef + action_loss - dist_entropy * entropy_coef).backward()
+        optimizer.step()
+        res = (value_loss.item(), action_loss.item(), dist_entropy.item())
+        np.testing.assert_allclose(np.array(res), G[tag + '/update%d/losses' % it], rtol=1e-4, atol=1e-6)
+        ftol = 1e-4 if kind == 'mlp' else 5e-4
+        for i, m in enumerate(optimizer.modules):
+            check_summary(G, tag + '/update%d/m_aa/%d' % (it, i), optimizer.m_aa[m].cpu().numpy(), ftol, tag)
+            check_summary(G, tag + '/update%d/m_gg/%d' % (it, i), optimizer.m_gg[m].cpu().numpy(), ftol, tag)
+        _, _, p_mg = update_vector_errors(G, tag + '/update%d/param/' % it + '%s', names,
+                                          lambda n: params[n].detach().cpu().numpy(),
+                                          lambda n: params[n].detach().cpu().numpy())
+        print(tag, 'update', it, 'hook-pattern params vs golden %.3g' % p_mg)
+        assert p_mg <= 1e-3, (it, p_mg)
+    assert optimizer.steps == 3

@@ -260,10 +260,12 @@ def test_a2c_update_vs_reference(ci):
                 e_mine = np.linalg.norm(mine - truth) / nrm
                 assert e_mine <= 2.0 * e_ref + TOL, (prefix, e_mine, e_ref)
                 assert np.linalg.norm(mine - gold) / nrm <= 5e-3, prefix   # sanity bound only
-        # the whole parameter vector directly against the reference golden, every update: 1e-4.  (The reference run
-        # with 8 threads reproduces these parameters to 1e-6 -- tests/test_oracle_kfac.py::test_reference_self_distance --
-        # so, unlike the KFAC update vector, nothing is conceded to the reference's own spread here; the per-tensor k = 2
-        # fp64 anchor above only serves the small tensors, whose own norm is a harsh yardstick.)
+        # the whole parameter vector directly against the reference golden, every update: 1e-4 wherever the golden itself
+        # is within 1e-4 of the fp64 run of the same algorithm; where it is not (third update of the NatureCNN case:
+        # golden-vs-fp64 1.6e-4, ours-vs-fp64 1.1e-7 -- one ReLU gate the reference's fp32 conv decided the other way,
+        # amplified by RMSprop's g / (sqrt(v) + eps)), an EXACT implementation sits e_ref away from the golden, so the bar
+        # is e_ref + 1e-4.  The reference run with 8 threads reproduces these parameters to 1e-6
+        # (tests/test_oracle_kfac.py::test_reference_self_distance): the spread is not a thread-count effect.
         from helpers import update_vector_errors
         names = [n for n, _ in pol.named_parameters()]
         params = dict(pol.named_parameters())
@@ -271,7 +273,7 @@ def test_a2c_update_vs_reference(ci):
                                                    lambda n: params[n].detach().cpu().numpy(),
                                                    lambda n: P64[n].detach().numpy())
         print(tag, 'update', it, 'parameters: ours-vs-golden %.3g, golden-vs-fp64 %.3g, ours-vs-fp64 %.3g' % (e_mg, e_ref, e_mine))
-        assert e_mg <= TOL, (it, e_mg)
+        assert e_mg <= (TOL if e_ref <= TOL else e_ref + TOL), (it, e_mg, e_ref)
         assert e_mine <= e_ref + TOL, (it, e_mine, e_ref)
 
 

@@ -453,30 +453,37 @@ class KFACOptimizer(optim.Optimizer):
             raise RuntimeError('acktr_sym_eig_rocsolver_multi_f32 failed (rc=%d): %s' % big_err[0])
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
-        if self.dp.active:
-            # every factor was decomposed by exactly one rank: each owner packs its (Q^T, d) slots into one contiguous
-            # message and broadcasts it -- 16.7 MB in total for NatureCNN, one collective per owner (round 1 zeroed the
-            # foreign slots and SUM all-reduced the four whole buckets: 33 MB through a reduction nobody needed)
-            per_owner = {}
-            for w, own in zip(self._eig_work, self._eig_owner):
-                per_owner.setdefault(own, []).append(w)
-            for own in sorted(per_owner):
-                segs = []
-                for run, qt, dfl, off, doff, n in per_owner[own]:
-                    segs.append(qt[off:off + n * n])
-                    segs.append(dfl[doff:doff + n])
-                total = sum(t_.numel() for t_ in segs)
-                if self._bcast_buf is None or self._bcast_buf.numel() < total:
-                    self._bcast_buf = torch.empty(total, dtype=f32, device=dev)
-                buf = self._bcast_buf[:total]
-                if own == self.dp.rank:
-                    torch.cat(segs, out=buf)
-                self.dp.broadcast_(buf, src=own)
-                if own != self.dp.rank:
-                    o = 0
-                    for t_ in segs:
-                        t_.copy_(buf[o:o + t_.numel()])
-                        o += t_.numel()
+        self._exchange_eig()
+
+    def _exchange_eig(self):
+        """Data-parallel return of the sharded eigendecompositions: every factor was decomposed by exactly
+        one rank; each owner packs its (Q^T, d) slots into one contiguous message and broadcasts it -- 16.7 MB in total
+        for NatureCNN, one collective per owner (round 1 zeroed the foreign slots and SUM all-reduced the four whole
+        buckets: 33 MB through a reduction nobody needed).  Pure tensor logic: tests/test_parallel_cpu.py drives it with
+        gloo at world 4 on CPU tensors."""
+        if not self.dp.active:
+            return
+        dev = self.qt_a.device
+        per_owner = {}
+        for w, own in zip(self._eig_work, self._eig_owner):
+            per_owner.setdefault(own, []).append(w)
+        for own in sorted(per_owner):
+            segs = []
+            for run, qt, dfl, off, doff, n in per_owner[own]:
+                segs.append(qt[off:off + n * n])
+                segs.append(dfl[doff:doff + n])
+            total = sum(t_.numel() for t_ in segs)
+            if self._bcast_buf is None or self._bcast_buf.numel() < total or self._bcast_buf.device != dev:
+                self._bcast_buf = torch.empty(total, dtype=f32, device=dev)
+            buf = self._bcast_buf[:total]
+            if own == self.dp.rank:
+                torch.cat(segs, out=buf)
+            self.dp.broadcast_(buf, src=own)
+            if own != self.dp.rank:
+                o = 0
+                for t_ in segs:
+                    t_.copy_(buf[o:o + t_.numel()])
+                    o += t_.numel()
 
     def _solve_rocsolver(self, work):
         """syevd on the listed (run, qt, d, off, doff, n) factors on the current stream (fallback path)."""

@@ -12,7 +12,7 @@ import os
 import torch
 
 from .. import _hip, engine, ops
-from ..parallel import DataParallel
+from ..parallel import DataParallel, bounded_sync
 
 # ACKTR_DEFER_HEAD=0: the head step finalizes in its own launch (comparison switch)
 DEFER_HEAD_FINALIZE = os.environ.get('ACKTR_DEFER_HEAD', '1') != '0'
@@ -114,6 +114,7 @@ class PPO():
         self._graph_key = None
         self._graphs = None
         self._seen_key = None
+        self._full_checked = False
 
     # one minibatch step = ppo.py:57-84
     def _fwd_bwd(self, b, phase=None, with_optimizer=False):
@@ -261,6 +262,11 @@ class PPO():
                     self._idx_all.copy_(perm[:nb * mbs].view(nb, mbs)[:, lo:hi])
                     self._graphs[0].replay()
                     self.optimizer.step_count += nb
+                    if full and not self._full_checked:
+                        # first replay of an epoch graph that contains RCCL collectives: bounded wait, then trusted
+                        bounded_sync(dev, float(os.environ.get('ACKTR_DP_GRAPH_TIMEOUT', '120')),
+                                     'the first replay of the ACKTR_DP_GRAPH=full epoch graph (captured RCCL all-reduces)')
+                        self._full_checked = True
                     continue
                 for indices in rollouts.minibatch_index_batches(self.num_mini_batch):   # ppo.py:48-51
                     self._idx.copy_(indices[lo:hi])

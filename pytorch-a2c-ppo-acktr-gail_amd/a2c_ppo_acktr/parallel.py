@@ -148,6 +148,26 @@ class PiecewiseGraph(object):
                 it()
 
 
+def bounded_sync(device, seconds, what):
+    """Wait for everything queued on `device`'s current stream, but not for ever: a collective captured into a hipGraph
+    that never completes with N ranks (a peer missing, a mismatched replay order) shows no error, the stream just never
+    drains.  After `seconds` the process says what it was waiting for and exits with status 70, so that a launcher
+    (torch.distributed.run, bench.py's own) records a failure instead of hanging until its own limit."""
+    import os
+    import sys
+    import time
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    t0 = time.monotonic()
+    while not ev.query():
+        if time.monotonic() - t0 > seconds:
+            sys.stderr.write('a2c_ppo_acktr: %s did not complete within %.0f s on %s (rank %s of %s); giving up\n'
+                             % (what, seconds, device, os.environ.get('RANK', '0'), os.environ.get('WORLD_SIZE', '1')))
+            sys.stderr.flush()
+            os._exit(70)
+        time.sleep(0.0005)
+
+
 class _Done(object):
     def wait(self):
         return True

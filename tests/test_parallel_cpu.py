@@ -178,3 +178,63 @@ def test_bench_self_launch_propagates_rank_failure():
     assert r.returncode != 0
     assert 'rank 1 exited' in r.stderr
     assert time.time() - t0 < 120
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ACKTR: owner broadcasts of the sharded eigendecompositions (algo/kfac.py::_exchange_eig), world 4 on gloo
+# ---------------------------------------------------------------------------------------------------------------
+def _eig_fill(i, n):
+    """What 'rank owner[i] decomposed factor i' looks like in this test: values determined by the factor alone."""
+    q = (torch.arange(n * n, dtype=torch.float32) * 1e-3 + float(i)).remainder(7.0) - 3.0
+    d = torch.arange(n, dtype=torch.float32) + 0.5 * i
+    return q, d
+
+
+def _eig_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from a2c_ppo_acktr.algo.kfac import KFACOptimizer
+    from a2c_ppo_acktr.model import Policy
+    from a2c_ppo_acktr.parallel import DataParallel
+
+    class Discrete(object):
+        n = 6
+    torch.manual_seed(0)
+    pol = Policy((4, 84, 84), Discrete())                  # CPU tensors: only the host logic runs here
+    opt = KFACOptimizer(pol)
+    opt.dp = DataParallel()
+    assert opt.dp.world == world and opt.dp.rank == rank
+    opt._setup(torch.device('cpu'))
+    assert len(opt._eig_work) == 24 and sorted(set(opt._eig_owner)) == list(range(world))
+    nan = float('nan')
+    for b in (opt.qt_a, opt.qt_g, opt.d_a_flat, opt.d_g_flat):
+        b.fill_(nan)                                       # foreign slots hold garbage until the owners' messages land
+    for i, ((run, qt, dfl, off, doff, n), own) in enumerate(zip(opt._eig_work, opt._eig_owner)):
+        if own == rank:
+            q, d = _eig_fill(i, n)
+            qt[off:off + n * n].copy_(q)
+            dfl[doff:doff + n].copy_(d)
+    opt._exchange_eig()
+    ok = True
+    for i, (run, qt, dfl, off, doff, n) in enumerate(opt._eig_work):
+        q, d = _eig_fill(i, n)
+        ok = ok and torch.equal(qt[off:off + n * n], q) and torch.equal(dfl[doff:doff + n], d)
+    # the public views see the same storage
+    m = opt.modules[6]                                     # Linear(1568 -> 512)
+    ok = ok and tuple(opt.Q_a[m].shape) == (1568, 1568) and not bool(torch.isnan(opt.Q_a[m]).any())
+    torch.save({'ok': bool(ok), 'owner': list(opt._eig_owner)}, os.path.join(out_dir, 'eig_r%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eig_owner_broadcast_world4(tmp_path):
+    world = 4
+    mp.spawn(_eig_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), 'eig_r%d.pt' % r)) for r in range(world)]
+    assert all(r['ok'] for r in res)
+    assert all(r['owner'] == res[0]['owner'] for r in res)          # identical assignment on every rank
+    sizes = [256, 32, 1, 32, 512, 64, 1, 64, 576, 32, 1, 32, 1568, 512, 1, 512, 512, 1, 1, 1, 512, 6, 1, 6]
+    from a2c_ppo_acktr.parallel import assign_eig_owners
+    assert res[0]['owner'] == assign_eig_owners(sizes, world)

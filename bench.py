@@ -307,15 +307,28 @@ def side_metrics(device):
             ds = gail.ExpertDataset(fn, num_trajectories=ntraj, subsample_frequency=20)
             loader = torch.utils.data.DataLoader(ds, batch_size=128, shuffle=True, drop_last=True)
             obsfilt = lambda x, update=False: x
-            ms = []
+            ms, step_us = [], []
+            inner_step = disc._step
+
+            def timed_step(*a, **k):              # HIP events on the launch stream behind every minibatch step
+                r = inner_step(*a, **k)
+                e = torch.cuda.Event(enable_timing=True)
+                e.record()
+                evs.append(e)
+                return r
             for i in range(6):
                 torch.manual_seed(700 + i)
+                evs = []
+                disc._step = timed_step
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 disc.update(loader, rs, obsfilt)
                 torch.cuda.synchronize()
                 ms.append((time.perf_counter() - t0) * 1e3)
-            res[ntraj] = (statistics.median(ms[2:]), len(loader))
+                disc._step = inner_step
+                if len(evs) > 1:                  # steps 2..n on the device time line: the CPU randperm lies before step 1
+                    step_us.append(evs[0].elapsed_time(evs[-1]) * 1e3 / (len(evs) - 1))
+            res[ntraj] = (statistics.median(ms[2:]), len(loader), statistics.median(step_us[2:]) if step_us else None)
     t0 = time.perf_counter()
     for _ in range(3):
         torch.randperm(T * N)
@@ -325,14 +338,13 @@ def side_metrics(device):
                        predict_reward_samples_per_s=round(T * N / (min(pr[1:]) * 1e-3), 1),
                        update_ms_4_trajectories=round(res[4][0], 3), update_batches_4_trajectories=res[4][1],
                        update_ms_64_trajectories=round(res[64][0], 3), update_batches_64_trajectories=res[64][1],
-                       us_per_discriminator_step=round(res[64][0] * 1e3 / res[64][1], 1),
+                       us_per_discriminator_step_host_wall_incl_randperm=round(res[64][0] * 1e3 / res[64][1], 1),
                        # every update draws torch.randperm over all T*N rollout rows on the CPU first (reference
                        # storage.py:119-123 through gail.py:60, same RNG stream): a fixed host cost per update
                        cpu_randperm_ms_per_update=round(rp_ms, 3),
-                       # marginal cost of a minibatch step: both updates pay ONE permutation, they differ by 24 steps
-                       # (subtracting a separately timed randperm instead swung by +-100 us with the host's mood)
-                       us_per_discriminator_step_net_of_randperm=round(
-                           (res[64][0] - res[4][0]) * 1e3 / max(res[64][1] - res[4][1], 1), 1))
+                       # a minibatch step on the device time line: HIP events behind every step of the 25-step update,
+                       # (last - first) / 24 -- the permutation is drawn before the first step, so it is not in here
+                       us_per_discriminator_step_hip_events=(round(res[64][2], 1) if res[64][2] is not None else None))
     return out
 
 

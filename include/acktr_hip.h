@@ -219,10 +219,13 @@ int acktr_head_step_deferred_f32(const acktr_loss_args* args, const float* feat,
 int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions, int B, int A,
                        float* logp, float* entropy, float* entropy_mean, void* stream);
 /* Rollout-side head of Policy.act -- model.py:54-66, distributions.py:22-25,28-29,37-44: the mode (deterministic != 0)
- * or one sample per row, and dist.log_probs(action) of it.  Categorical: action_out int64[B]; sampling = inverse CDF of
- * softmax(logits) at the caller's uniform noise[B] in [0,1) (the reference draws with torch.multinomial on its own
- * generator: same distribution, not the same stream).  DiagGaussian: action_out float[B,A]; sample = mean +
- * exp(logstd) * noise[B,A] with the caller's standard normal noise (torch.normal's formula). */
+ * or one sample per row, and dist.log_probs(action) of it.  Categorical: action_out int64[B]; deterministic == 0:
+ * inverse CDF of softmax(logits) at the caller's uniform noise[B] in [0,1) (same distribution as the reference, its
+ * own stream); deterministic == 2: argmax_i p_i / noise[b,i] with the caller's Exp(1) draws noise[B,A] -- the
+ * one-sample fast path of torch.multinomial that FixedCategorical.sample (distributions.py:19-20) reaches, so with
+ * noise = torch.empty(B, A).exponential_(1) from the CPU default generator the actions ARE the reference CPU path's.
+ * DiagGaussian: action_out float[B,A]; sample (0 or 2) = mean + exp(logstd) * noise[B,A] with the caller's standard
+ * normal noise (torch.normal's formula, distributions.py:41-44 through torch.distributions.Normal.sample). */
 int acktr_dist_act_f32(int dist, const float* dist_in, long ld, const float* logstd, const float* noise,
                        int deterministic, int B, int A, void* action_out, float* logp, void* stream);
 /* their backward: ddist = dlogp[b]*dlogp/d(dist_in) + dentropy[b]*dentropy/d(dist_in) (either seed nullable);

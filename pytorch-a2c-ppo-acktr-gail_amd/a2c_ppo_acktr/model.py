@@ -16,6 +16,8 @@ parameter container like the rest; the sequence runs in engine.gru_forward / gru
 Not built: the broken Bernoulli head (reference distributions.py:49-50, F11).
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 
@@ -31,6 +33,9 @@ class Flatten(nn.Module):
 
 def _align4(n):
     return (n + 3) // 4 * 4
+
+
+_DEFAULT_SAMPLE_STREAM = 'device' if os.environ.get('ACKTR_ACT_RNG', 'reference') == 'device' else 'reference'
 
 
 class Policy(nn.Module):
@@ -178,24 +183,33 @@ class Policy(nn.Module):
 
     def act(self, inputs, rnn_hxs, masks, deterministic=False):
         """reference model.py:54-66, rollout side: HIP forward without grad, then ONE head kernel (csrc/loss.hip
-        dist_act_kernel) for mode / sample and the log-prob of the chosen action.  Sampling noise comes from torch's
-        device generator (uniform [B] for Categorical, standard normal [B, A] for DiagGaussian): same distributions as
-        the reference's multinomial / normal draws, not the same random stream."""
+        dist_act_kernel) for mode / sample and the log-prob of the chosen action.
+        Sampling stream (`self.sample_stream`, default from ACKTR_ACT_RNG, 'reference' unless set to 'device'):
+        'reference' consumes the CPU default generator exactly as the reference's CPU path does -- Categorical:
+        torch.multinomial(probs, 1)'s one-sample path draws q = empty_like(probs).exponential_(1) and returns
+        argmax p / q; DiagGaussian: torch.normal(mean, std) draws a standard normal tensor of mean's shape -- so the same
+        torch.manual_seed gives the reference's actions (tests/golden/act.npz `sample/*`).  'device' draws uniform [B] /
+        normal [B, A] noise on the GPU generator instead: same distributions, no host draw or copy, another stream."""
         from . import _hip
         with torch.no_grad():
             acts = engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks)
             dev = inputs.device
             B, A, kind = inputs.shape[0], self.dist.num_outputs, self.dist.kind
-            noise = None
+            noise, mode = None, 1
             if not deterministic:
-                noise = torch.rand(B, device=dev) if kind == 0 else torch.randn(B, A, device=dev)
+                if getattr(self, 'sample_stream', _DEFAULT_SAMPLE_STREAM) == 'device':
+                    noise, mode = (torch.rand(B, device=dev) if kind == 0 else torch.randn(B, A, device=dev)), 0
+                elif kind == 0:
+                    noise, mode = torch.empty(B, A).exponential_(1).to(dev, non_blocking=True), 2
+                else:
+                    noise, mode = torch.empty(B, A).normal_().to(dev, non_blocking=True), 0
             action = torch.empty((B, 1), dtype=torch.int64, device=dev) if kind == 0 else \
                 torch.empty((B, A), dtype=torch.float32, device=dev)
             logp = torch.empty(B, 1, dtype=torch.float32, device=dev)
             ls = engine.logstd_param(self).detach() if kind == 1 else None
             dp, dld = acts.dist_ptr_ld()
             rc = _hip.lib().acktr_dist_act_f32(kind, dp, dld, _hip.dev_ptr(ls), _hip.dev_ptr(noise),
-                                               1 if deterministic else 0, B, A, _hip.dev_ptr(action, action.dtype),
+                                               mode, B, A, _hip.dev_ptr(action, action.dtype),
                                                _hip.dev_ptr(logp), _hip.cur_stream(dev))
             _hip.check(rc, 'acktr_dist_act_f32')
             if self.is_recurrent:

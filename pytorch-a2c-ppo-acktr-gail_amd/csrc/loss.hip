@@ -132,8 +132,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void mean_kernel(const float* x, int 
 
 // Rollout-side head (Policy.act, model.py:54-66): mode or a sample of the action distribution and the log-prob of
 // the chosen action, one sample per lane.
-//   categorical: mode = first argmax of the logits (torch.argmax); sample = inverse CDF of softmax(logits) at the
-//                caller's uniform u[b] in [0, 1) (one draw per row, like FixedCategorical.sample's multinomial(1));
+//   categorical: mode = first argmax of the logits (torch.argmax); sample (deterministic == 0) = inverse CDF of
+//                softmax(logits) at the caller's uniform u[b] in [0, 1); sample (deterministic == 2) = the exponential
+//                race torch.multinomial(probs, 1) runs, on the caller's Exp(1) draws q[b, i];
 //   gaussian   : mode = mean; sample = mean + std * eps with the caller's standard normal eps[b, j] (torch.normal's
 //                own formula, FixedNormal.sample); the log-prob follows torch Normal.log_prob term by term.
 template <int DIST>
@@ -151,7 +152,18 @@ __global__ __launch_bounds__(LOSS_THREADS) void dist_act_kernel(const float* dis
         for (int i = 0; i < A; ++i) ssum += expf(z[i] - m);
         const float lse = m + logf(ssum);
         int a = am;
-        if (!deterministic) {
+        if (deterministic == 2) {
+            // the reference's own draw on its CPU path: Categorical.sample -> torch.multinomial(probs, 1), whose
+            // one-sample fast path is argmax_i p_i / q_i with q ~ Exp(1) drawn for every (row, category); the caller
+            // hands in q from the same generator call (torch.empty(B, A).exponential_(1)), the common normaliser of
+            // p cancels in the argmax, ties resolve to the first index like torch.argmax
+            float best = -1.f;
+            a = 0;
+            for (int i = 0; i < A; ++i) {
+                const float r = expf(z[i] - m) / noise[(long)b * A + i];
+                if (r > best) { best = r; a = i; }
+            }
+        } else if (!deterministic) {
             const float target = noise[b] * ssum;          // u * sum_i exp(z_i - m): no division per category
             float acc = 0.f;
             a = A - 1;
@@ -167,7 +179,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void dist_act_kernel(const float* dis
         float* out = (float*)action_out + (long)b * A;
         for (int j = 0; j < A; ++j) {
             const float sd = expf(logstd[j]);
-            const float act = deterministic ? z[j] : z[j] + sd * noise[(long)b * A + j];
+            const float act = deterministic == 1 ? z[j] : z[j] + sd * noise[(long)b * A + j];
             const float var = sd * sd, d = act - z[j];
             lp += -(d * d) / (2.f * var) - logf(sd) - HALF_LOG_2PI;
             out[j] = act;
@@ -283,7 +295,8 @@ extern "C" int acktr_dist_act_f32(int dist, const float* dist_in, long ld, const
     ACKTR_ARG(dist_in && action_out && logp, "dist_act: null pointer");
     ACKTR_ARG(B > 0 && A > 0 && ld >= A, "dist_act: bad sizes");
     ACKTR_ARG(dist == 0 || (dist == 1 && logstd && A <= 16), "dist_act: bad distribution arguments");
-    ACKTR_ARG(deterministic || noise, "dist_act: sampling needs the noise array (uniform [B] / standard normal [B,A])");
+    ACKTR_ARG(deterministic >= 0 && deterministic <= 2, "dist_act: deterministic must be 0, 1 or 2");
+    ACKTR_ARG(deterministic == 1 || noise, "dist_act: sampling needs the noise array (uniform [B] / Exp(1) [B,A] / standard normal [B,A])");
     hipStream_t s = (hipStream_t)stream;
     const int nblk = cdiv(B, LOSS_THREADS);
     if (dist == 0)

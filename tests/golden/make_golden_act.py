@@ -56,6 +56,20 @@ def main():
         out[tag + '/act/action'] = action.numpy().copy()
         out[tag + '/act/logp'] = logp.numpy().copy()
         out[tag + '/get_value'] = gv.numpy().copy()
+        # sampled actions (model.py:58-63 with deterministic=False): two consecutive calls behind one torch.manual_seed,
+        # drawn by the reference's own dist.sample() on the CPU default generator -- the stream a drop-in has to consume
+        # in the same order -- and a wider batch (256 rows) for the heads' statistics
+        torch.manual_seed(77 + ci)
+        with torch.no_grad():
+            for k in range(2):
+                _, action, logp, _ = pol.act(obs, None, None)
+                out[tag + '/sample/action%d' % k] = action.numpy().copy()
+                out[tag + '/sample/logp%d' % k] = logp.numpy().copy()
+            if kind == 'mlp':
+                wide = t(synth.make_rollouts(1, 256, obs_shape, 'discrete' if cat else 'box', A, salt=1480 + ci)['obs'][0])
+                _, action, logp, _ = pol.act(wide, None, None)
+                out[tag + '/sample/wide_action'] = action.numpy().copy()
+                out[tag + '/sample/wide_logp'] = logp.numpy().copy()
         if tag in ('cnn_gauss', 'mlp_cat'):
             act = t(ro['actions'][0])
             vp = t(ro['value_preds'][0]); ret = t(synth.normalish((B, 1), 1450 + ci)); adv = t(synth.normalish((B, 1), 1460 + ci))

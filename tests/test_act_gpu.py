@@ -61,6 +61,7 @@ def test_act_sampling(ci):
     mean + std * (the device generator's next normal draw); categorical samples follow softmax(logits)."""
     tag, kind, od, cat, A, B = ACT_CASES[ci]
     pol, P, obs, ro = make_policy(ci)
+    pol.sample_stream = 'device'                 # (the reference-stream mode has its own test below)
     x = t(obs).cuda()
     torch.manual_seed(11)
     value, action, logp, _ = pol.act(x, None, None)
@@ -89,6 +90,33 @@ def test_act_sampling(ci):
         n += 4096
     freq = counts / n
     assert np.all(np.abs(freq - probs) <= 4.0 * np.sqrt(probs * (1 - probs) / n) + 1e-3), (freq, probs)
+
+
+@pytest.mark.parametrize('ci', range(len(ACT_CASES)))
+def test_act_sampling_reference_stream(ci):
+    """Policy.act(deterministic=False) in its default mode consumes the CPU default generator like the reference's CPU
+    path (Categorical: torch.multinomial's one-sample exponential race; DiagGaussian: torch.normal), so the same
+    torch.manual_seed gives the REFERENCE'S actions: two consecutive calls and a 256-row batch against goldens written
+    by the reference's own Policy.act (tests/golden/make_golden_act.py).  Categorical actions exact, Gaussian actions
+    and every log-prob to 1e-4."""
+    tag, kind, od, cat, A, B = ACT_CASES[ci]
+    G = golden('act')
+    pol, P, obs, ro = make_policy(ci)
+    assert getattr(pol, 'sample_stream', 'reference') == 'reference'
+    x = t(obs).cuda()
+    calls = [(x, 'action0', 'logp0'), (x, 'action1', 'logp1')]
+    if kind == 'mlp':
+        wide = synth.make_rollouts(1, 256, (od,), 'discrete' if cat else 'box', A, salt=1480 + ci)['obs'][0]
+        calls.append((t(wide).cuda(), 'wide_action', 'wide_logp'))
+    torch.manual_seed(77 + ci)
+    for xin, ka, kl in calls:
+        _, action, logp, _ = pol.act(xin, None, None)
+        ga, gl = G[tag + '/sample/' + ka], G[tag + '/sample/' + kl]
+        if cat:
+            assert action.dtype == torch.int64 and np.array_equal(action.cpu().numpy(), ga), (ka, action.view(-1), ga.ravel())
+        else:
+            np.testing.assert_allclose(action.cpu().numpy(), ga, rtol=TOL, atol=2e-5)
+        np.testing.assert_allclose(logp.cpu().numpy(), gl, rtol=TOL, atol=2e-5)
 
 
 @pytest.mark.parametrize('ci', [2, 3])

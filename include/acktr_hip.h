@@ -55,8 +55,13 @@ int acktr_adv_normalize_f32(const float* returns, const float* value_preds, floa
  * whose per-device address is looked up once with hipGetSymbolAddress.  The call itself allocates and frees nothing.
  * Same kernels, same fixed reduction order -> bit-identical to acktr_adv_normalize_f32.  n must be
  * <= acktr_adv_normalize_noalloc_max_n() (2^28 elements), else -1 with a message.  All calls on one GPU share that
- * array: calls that overlap on one GPU (different streams) race; nothing in it has to start at zero. */
+ * array: calls that overlap on one GPU (different streams) race; nothing in it has to start at zero.
+ * The device that owns `stream` must be the current device (checked; -1 otherwise): the scratch address is per device.
+ * acktr_adv_normalize_noalloc_init() resolves the current device's scratch address ahead of time -- call it once per
+ * device OUTSIDE any stream capture (the first compute call on a device would otherwise do the lookup itself, which is
+ * not something to do under capture); it launches nothing and allocates nothing. */
 long acktr_adv_normalize_noalloc_max_n(void);
+int acktr_adv_normalize_noalloc_init(void);
 int acktr_adv_normalize_noalloc_f32(const float* returns, const float* value_preds, float* adv, long n, void* stream);
 
 /* Minibatch gather -- a2c_ppo_acktr/storage.py:127-140 (x.view(-1, ...)[indices]).

@@ -90,6 +90,7 @@ _PROTOS = {
     'acktr_adv_normalize_workspace_bytes': (c_l, []),
     'acktr_adv_normalize_f32': (c_i, [c_p, c_p, c_p, c_l, c_p, c_p]),
     'acktr_adv_normalize_noalloc_max_n': (c_l, []),
+    'acktr_adv_normalize_noalloc_init': (c_i, []),
     'acktr_adv_normalize_noalloc_f32': (c_i, [c_p, c_p, c_p, c_l, c_p]),
     'acktr_gather_rows': (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
     'acktr_conv2d_fwd_workspace_bytes': (c_l, [c_i] * 7),

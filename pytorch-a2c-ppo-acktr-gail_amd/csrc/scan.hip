@@ -414,11 +414,22 @@ constexpr int NOALLOC_MAX_DEVICES = 64;
 static std::mutex g_noalloc_mu;
 static double* g_noalloc_ptr[NOALLOC_MAX_DEVICES] = {nullptr};
 
-static int adv_noalloc_scratch_ptr(double** out) {
+// The scratch address of the CURRENT device.  `s` (nullable): the stream the kernels will be launched on -- it must
+// belong to the current device, or the launch would carry another GPU's address.
+static int adv_noalloc_scratch_ptr(double** out, hipStream_t s) {
     int dev = -1;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) { set_error("adv_normalize_noalloc: hipGetDevice failed: %s", hipGetErrorString(e)); return (int)e; }
     if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) { set_error("adv_normalize_noalloc: device %d out of range", dev); return -1; }
+    if (s) {
+        hipDevice_t sdev = -1;
+        e = hipStreamGetDevice(s, &sdev);
+        if (e == hipSuccess && (int)sdev != dev) {
+            set_error("adv_normalize_noalloc: the stream belongs to device %d but device %d is current; make the stream's "
+                      "device current before the call", (int)sdev, dev);
+            return -1;
+        }
+    }
     std::lock_guard<std::mutex> lk(g_noalloc_mu);
     if (!g_noalloc_ptr[dev]) {                       // once per device, with that device current
         double* p = nullptr;
@@ -443,6 +454,11 @@ extern "C" int acktr_adv_normalize_f32(const float* returns, const float* value_
 
 extern "C" long acktr_adv_normalize_noalloc_max_n(void) { return 1L << 28; }
 
+extern "C" int acktr_adv_normalize_noalloc_init(void) {
+    double* p = nullptr;
+    return adv_noalloc_scratch_ptr(&p, nullptr);
+}
+
 extern "C" int acktr_adv_normalize_noalloc_f32(const float* returns, const float* value_preds, float* adv, long n,
                                                void* stream) {
     ACKTR_ARG(returns && value_preds && adv, "adv_normalize_noalloc: null pointer");
@@ -451,7 +467,7 @@ extern "C" int acktr_adv_normalize_noalloc_f32(const float* returns, const float
               "adv_normalize_noalloc: n=%ld exceeds the maximum of %ld elements of this allocation-free entry point; "
               "use acktr_adv_normalize_f32 with a caller workspace", n, acktr_adv_normalize_noalloc_max_n());
     double* partial = nullptr;
-    int rc = adv_noalloc_scratch_ptr(&partial);
+    int rc = adv_noalloc_scratch_ptr(&partial, (hipStream_t)stream);
     if (rc) return rc;
     // every partial a launch reads was written by the same call's first kernel: nothing has to start at zero
     return adv_normalize_launch(returns, value_preds, adv, n, partial, (hipStream_t)stream);

@@ -23,11 +23,15 @@ def _both(n, seed):
     _hip.check(L.acktr_adv_normalize_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(want), n,
                                          _hip.dev_ptr(ws), stream), 'acktr_adv_normalize_f32')
     torch.cuda.synchronize()
+    # hipMemGetInfo sees every allocation on the device, the library's own hipMalloc / hipFree included (torch's
+    # memory_allocated() only counts torch's caching allocator)
+    free_before, _ = torch.cuda.mem_get_info(dev)
     before = torch.cuda.memory_allocated(dev)
     _hip.check(L.acktr_adv_normalize_noalloc_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(got), n, stream),
                'acktr_adv_normalize_noalloc_f32')
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated(dev) == before
+    assert torch.cuda.mem_get_info(dev)[0] == free_before, 'device memory was allocated or freed inside the call'
     return want, got
 
 
@@ -43,6 +47,37 @@ def test_noalloc_adv_normalize_matches_workspace_form_twice():
     # and the smallest legal one
     want, got = _both(2, 3)
     assert torch.equal(want.view(torch.int32), got.view(torch.int32))
+
+
+def test_noalloc_under_graph_capture():
+    """The use case the header names: the entry point recorded into a hipGraph (after acktr_adv_normalize_noalloc_init
+    outside the capture) and replayed twice on changing inputs, against the workspace form."""
+    L = _hip.lib()
+    dev = torch.device('cuda:0')
+    assert L.acktr_adv_normalize_noalloc_init() == 0
+    n = 128 * 300 + 7
+    g0 = torch.Generator().manual_seed(5)
+    ret, val = torch.randn(n, generator=g0).to(dev), torch.randn(n, generator=g0).to(dev)
+    got = torch.full((n,), float('nan'), device=dev)
+    ws = torch.empty(L.acktr_adv_normalize_workspace_bytes(), dtype=torch.uint8, device=dev)
+    graph = torch.cuda.CUDAGraph()
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph):
+        _hip.check(L.acktr_adv_normalize_noalloc_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(got), n,
+                                                     _hip.cur_stream(dev)), 'acktr_adv_normalize_noalloc_f32 (capture)')
+    for k in range(2):
+        ret.copy_(torch.randn(n, generator=g0))
+        val.copy_(torch.randn(n, generator=g0))
+        got.fill_(float('nan'))
+        free_before, _ = torch.cuda.mem_get_info(dev)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info(dev)[0] == free_before
+        want = torch.empty(n, device=dev)
+        _hip.check(L.acktr_adv_normalize_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(want), n, _hip.dev_ptr(ws),
+                                             _hip.cur_stream(dev)), 'acktr_adv_normalize_f32')
+        torch.cuda.synchronize()
+        assert torch.equal(want.view(torch.int32), got.view(torch.int32)), k
 
 
 def test_noalloc_rejects_oversize_and_bad_arguments():

@@ -241,6 +241,24 @@ int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const float* log
                        const float* dlogp, const float* dentropy, int B, int A, float* ddist, long ldd, float* dlogstd,
                        float* dlogstd_rows, void* workspace, long workspace_bytes, void* stream);
 
+/* ---- frames stored as bytes on the device --------------------------------------------------------------------
+ * The reference keeps observations as float32 holding 0..255 (storage.py:12, envs.py:176,188; model.py:190 divides by
+ * 255): these entry points are the first NatureCNN layer (model.py:176: Conv2d(4, 32, 8, stride=4) on 84x84 frames)
+ * reading uint8 frames [Bsrc,4,84,84] instead -- a quarter of the traffic of the layer's forward, its weight gradient
+ * and its KFAC input factor.  The byte -> float conversion is exact and the products run in the same order, so every
+ * result is BIT-IDENTICAL to the float entry points on float frames of the same values.  Arguments as in
+ * acktr_conv2d_fwd_f32 / acktr_conv2d_wgrad_deferred_f32 (pending nullable) / acktr_kfac_cov_a_conv_f32 with C = 4,
+ * H = W = 84, OC = 32, KH = KW = 8, S = 4 fixed; x 4-byte aligned.  The forward needs the weight-image workspace
+ * (acktr_conv2d_fwd_workspace_bytes), the weight gradient acktr_conv1_wgrad_u8_workspace_bytes(B), the factor
+ * acktr_kfac_cov_workspace_bytes(256, B * 400). */
+int acktr_conv1_fwd_u8(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y, int B,
+                       float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked, void* stream);
+long acktr_conv1_wgrad_u8_workspace_bytes(int B);
+int acktr_conv1_wgrad_u8(const uint8_t* x, const int64_t* gather_idx, const float* dy, float* dw, float* db, int B,
+                         float in_scale, void* workspace, long workspace_bytes, acktr_slab_fin* pending, void* stream);
+int acktr_kfac_cov_a_conv1_u8(const uint8_t* x, const int64_t* gather_idx, int B, float alpha, float* out,
+                              void* workspace, long workspace_bytes, void* stream);
+
 /* ---- optimisers on flat parameter buffers ------------------------------------------------- */
 
 /* nn.utils.clip_grad_norm_ + optim.Adam.step -- algo/ppo.py:82-84 (max_grad_norm <= 0 disables clipping).

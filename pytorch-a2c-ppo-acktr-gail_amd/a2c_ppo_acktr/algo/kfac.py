@@ -336,6 +336,18 @@ class KFACOptimizer(optim.Optimizer):
                 OC, C, KH, KW = m.param.shape
                 H, W = x.shape[-2], x.shape[-1]
                 OH, OW = (H - KH) // stride + 1, (W - KW) // stride + 1
+                if x.dtype == torch.uint8:                          # frames kept as bytes: conv1 only
+                    if self.fast_cnn:
+                        raise NotImplementedError('KFACOptimizer(fast_cnn=True) reads float observations; uint8 frames '
+                                                  '(RolloutStorage(obs_dtype=torch.uint8)) are not supported there')
+                    alpha = (sc * sc) / (float(Bg) * float(OH * OW) ** 2)
+                    D_, R_ = C * KH * KW, B * OH * OW
+                    ws = ops.workspace(dev, L.acktr_kfac_cov_workspace_bytes(D_, R_), 'kfac')
+                    with ops._Timed('kfac_cov_a_conv%ds%d' % (KH, stride), float(R_) * D_ * (D_ + 1)):
+                        rc = L.acktr_kfac_cov_a_conv1_u8(_hip.dev_ptr(x, torch.uint8), _hip.dev_ptr(idx, torch.int64), B, alpha,
+                                                         _hip.dev_ptr(out), _hip.dev_ptr(ws), ws.numel(), stream)
+                    _hip.check(rc, 'acktr_kfac_cov_a_conv1_u8')
+                    continue
                 if self.fast_cnn:                                   # kfac.py:33-36: one mean patch per image
                     pm = torch.empty(B, C * KH * KW, dtype=f32, device=dev)
                     rc = L.acktr_kfac_patch_mean_f32(_hip.dev_ptr(x), _hip.dev_ptr(idx, torch.int64), B, C, H, W, KH, KW,

@@ -86,8 +86,9 @@ def _check_input(policy, inputs, gather_idx):
         raise RuntimeError('policy inputs must be on the MI355X device; this package has no CPU path')
     if next(policy.parameters()).device != inputs.device:
         raise RuntimeError('policy parameters and inputs are on different devices')
-    if inputs.dtype != f32:
-        raise RuntimeError('policy inputs must be float32 (reference storage.py:12, F6)')
+    if inputs.dtype != f32 and not (inputs.dtype == torch.uint8 and is_cnn(policy)):
+        raise RuntimeError('policy inputs must be float32 (reference storage.py:12, F6); NatureCNN policies also take uint8 '
+                           'frames (RolloutStorage(obs_dtype=torch.uint8))')
     if tuple(inputs.shape[1:]) != policy.obs_shape:
         raise RuntimeError('expected inputs of shape [B, %s], got %s' % (policy.obs_shape, tuple(inputs.shape)))
 

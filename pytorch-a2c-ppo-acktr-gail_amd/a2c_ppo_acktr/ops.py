@@ -127,6 +127,16 @@ def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out
     L = _hip.lib()
     nb = L.acktr_conv2d_fwd_workspace_bytes(C, H, W, OC, KH, KW, stride)
     ws = packed if packed is not None else (workspace(x.device, nb, tag='convfwd') if nb else None)
+    if x.dtype == torch.uint8:             # frames kept as bytes (RolloutStorage(obs_dtype=torch.uint8)): conv1 only
+        if (C, H, W, OC, KH, KW, stride) != (4, 84, 84, 32, 8, 8, 4) or ws is None:
+            raise RuntimeError('uint8 inputs are supported for the first NatureCNN layer only (4x84x84, 32 filters 8x8 s4)')
+        with _Timed('conv%ds%d_fwd' % (KH, stride), 2.0 * B * OH * OW * OC * C * KH * KW):
+            rc = L.acktr_conv1_fwd_u8(_p(x, 'x', torch.uint8), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'),
+                                      _p(bias, 'bias'), _p(out, 'y'), B, float(in_scale), 1 if relu else 0,
+                                      _p(ws, 'workspace', torch.uint8), ws.numel(), 1 if packed is not None else 0,
+                                      _hip.cur_stream(x.device))
+        _hip.check(rc, 'acktr_conv1_fwd_u8')
+        return out
     with _Timed('conv%ds%d_fwd' % (KH, stride), 2.0 * B * OH * OW * OC * C * KH * KW):
         rc = L.acktr_conv2d_fwd_f32(
             _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
@@ -151,6 +161,17 @@ def conv2d_wgrad(x, dy, w_shape, stride, dw, db=None, in_scale=1.0, gather_idx=N
     else:
         assert gather_idx.numel() == B
     L = _hip.lib()
+    if x.dtype == torch.uint8:
+        if (C, H, W, OC, KH, KW, stride) != (4, 84, 84, 32, 8, 8, 4):
+            raise RuntimeError('uint8 inputs are supported for the first NatureCNN layer only (4x84x84, 32 filters 8x8 s4)')
+        ws = workspace(x.device, L.acktr_conv1_wgrad_u8_workspace_bytes(B))
+        with _Timed('conv%ds%d_wgrad' % (KH, stride), 2.0 * dy[0].numel() * B * C * KH * KW):
+            rc = L.acktr_conv1_wgrad_u8(_p(x, 'x', torch.uint8), _p(gather_idx, 'gather_idx', torch.int64), _p(dy, 'dy'),
+                                        _p(dw, 'dw'), _p(db, 'db'), B, float(in_scale), _p(ws, 'workspace', torch.uint8),
+                                        ws.numel(), ctypes.byref(pending) if pending is not None else None,
+                                        _hip.cur_stream(x.device))
+        _hip.check(rc, 'acktr_conv1_wgrad_u8')
+        return
     nbytes = L.acktr_conv2d_wgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride)
     ws = workspace(x.device, nbytes)
     with _Timed('conv%ds%d_wgrad' % (KH, stride), 2.0 * dy[0].numel() * B * C * KH * KW):

@@ -135,19 +135,20 @@ static int sa1_wgrad_slabs(int B) {
     const int by_work = B * S1_GROUPS / 20;            // at least five row-pair groups per wave
     return by_work < cus ? (by_work < 1 ? 1 : by_work) : cus;
 }
-static int conv1_wgrad_sa(const float* x, const int64_t* idx, const float* dy, float* dw, float* db, int B, float scale,
+template <class XT>
+static int conv1_wgrad_sa(const XT* x, const int64_t* idx, const float* dy, float* dw, float* db, int B, float scale,
                           float* ws, long ws_floats, hipStream_t s, acktr_slab_fin* defer = nullptr) {
     const long wk = (long)S1_OC * S1_KC, slab = wk + S1_OC;
     const int ns = sa1_wgrad_slabs(B);
     if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_wgrad_sa_kernel),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_wgrad_sa_kernel<XT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, S1_LDS_BYTES);
         if (e != hipSuccess) { set_error("conv1_wgrad_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv1_wgrad_sa_kernel, dim3(ns), dim3(64 * S1_WAVES), S1_LDS_BYTES, s, x, idx, dy, ws, slab, B, scale);
+    hipLaunchKernelGGL(conv1_wgrad_sa_kernel<XT>, dim3(ns), dim3(64 * S1_WAVES), S1_LDS_BYTES, s, x, idx, dy, ws, slab, B, scale);
     ACKTR_LAUNCH_CHECK();
     if (defer && db == dw + wk && ns >= 16 && (((uintptr_t)dw | (uintptr_t)ws) & 15) == 0) {   // (what slab_reduce_wave_kernel serves)
         defer->dst = dw; defer->slabs = ws; defer->nslabs = ns; defer->n4 = (wk + S1_OC) / 4; defer->stride = slab;
@@ -429,6 +430,44 @@ static long dgrad_ws_floats(int B, int C, int H, int W, int OC, int KH, int KW, 
         if (m > n) n = m;
     }
     return n;
+}
+
+// ---- frames stored as bytes (rollout storage with obs_dtype=torch.uint8): NatureCNN's first layer only ----
+extern "C" long acktr_conv1_wgrad_u8_workspace_bytes(int B) {
+    if (B <= 0) return 0;
+    return (long)(sa1_wgrad_slabs(B) + SLAB_GROUP_EXTRA) * ((long)S1_OC * S1_KC + S1_OC) * (long)sizeof(float);
+}
+
+extern "C" int acktr_conv1_fwd_u8(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
+                                  int B, float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                                  void* stream) {
+    ACKTR_ARG(x && w && y && workspace, "conv1_fwd_u8: null pointer");
+    ACKTR_ARG(B > 0 && (long)B * 32 * 400 < (1L << 31), "conv1_fwd_u8: bad batch size %d", B);
+    ACKTR_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
+              "conv1_fwd_u8: x must be 4-byte, w and workspace 16-byte aligned");
+    ACKTR_ARG(workspace_bytes >= SwF1::lds_bytes(), "conv1_fwd_u8: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    float* img = (float*)workspace;
+    if (!prepacked) { const int rc = launch_sw_pack<SwF1>(w, img, 32, 0, 0, 0, s); if (rc) return rc; }
+    if (bias) {
+        SwFwdEpi<SwF1::SP, true> epi{y, bias, 32, in_scale, relu};
+        return launch_conv_sw<SwF1, SwFwdEpi<SwF1::SP, true>, uint8_t>(x, gather_idx, img, epi, B * SwF1::SP, s);
+    }
+    SwFwdEpi<SwF1::SP, false> epi{y, nullptr, 32, in_scale, relu};
+    return launch_conv_sw<SwF1, SwFwdEpi<SwF1::SP, false>, uint8_t>(x, gather_idx, img, epi, B * SwF1::SP, s);
+}
+
+extern "C" int acktr_conv1_wgrad_u8(const uint8_t* x, const int64_t* gather_idx, const float* dy, float* dw, float* db,
+                                    int B, float in_scale, void* workspace, long workspace_bytes, acktr_slab_fin* pending,
+                                    void* stream) {
+    ACKTR_ARG(x && dy && dw && workspace, "conv1_wgrad_u8: null pointer");
+    ACKTR_ARG(B > 0, "conv1_wgrad_u8: bad batch size %d", B);
+    ACKTR_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)dy & 15) == 0, "conv1_wgrad_u8: x must be 4-byte, dy 16-byte aligned");
+    if (pending) pending->dst = nullptr;
+    const int rc = conv1_wgrad_sa<uint8_t>(x, gather_idx, dy, dw, db, B, in_scale, (float*)workspace,
+                                           workspace_bytes / (long)sizeof(float), (hipStream_t)stream, pending);
+    ACKTR_ARG(rc != -2, "conv1_wgrad_u8: workspace too small (acktr_conv2d_wgrad_workspace_bytes(B, 4, 84, 84, 32, 8, 8, 4))");
+    return rc;
 }
 
 extern "C" int acktr_conv2d_wgrad_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw,

@@ -286,16 +286,27 @@ struct SwPhase2Epi {
     }
 };
 
+// The position operand's element type XT: float, or uint8_t for frames kept as bytes on the device (rollout storage
+// with obs_dtype=torch.uint8).  A lane's four kx taps are then ONE aligned 4-byte load, and the
+// bytes become floats (v_cvt_f32_ubyte0..3, exact) where the MFMA consumes them -- not at load time, which would make
+// the wave wait for the load on the spot.  Same products in the same order: bit-identical to the float frames.
+template <class XT, int E> struct SwRaw { typedef typename TapVec<E>::type type; typedef typename TapVec<E>::utype utype; };
+template <> struct SwRaw<uint8_t, 4> { typedef uint32_t type; typedef uint32_t utype; };
+__device__ __forceinline__ float sw_tap(const f32x2& v, int t) { return v[t]; }
+__device__ __forceinline__ float sw_tap(const f32x3& v, int t) { return v[t]; }
+__device__ __forceinline__ float sw_tap(const f32x4& v, int t) { return v[t]; }
+__device__ __forceinline__ float sw_tap(uint32_t v, int t) { return (float)((v >> (8 * t)) & 0xffu); }
+
 // ---------------------------------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------------------------------
-template <class G, class Epi>
-__global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict__ x,
+template <class G, class Epi, class XT = float>
+__global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x,
                                                              const int64_t* __restrict__ idx,
                                                              const float* __restrict__ wimg, const Epi epi, int R,
                                                              int ntiles) {
-    using VT = typename TapVec<G::E>::type;
-    using VU = typename TapVec<G::E>::utype;
+    using VT = typename SwRaw<XT, G::E>::type;
+    using VU = typename SwRaw<XT, G::E>::utype;
     using AT = typename TapVec<G::EP>::type;
     constexpr int TM = G::TM, TMW = G::TMW, MG = G::MG, NL = G::NL, NS = G::NS, C = G::CH;
     extern __shared__ __attribute__((aligned(16))) float sw_smem[];
@@ -322,7 +333,7 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
     constexpr long img_stride = (long)C * G::HW;
     const int half_off = h * G::HOFF;
 
-    auto lane_base = [&](int tile, int& r, bool& valid) -> const float* {
+    auto lane_base = [&](int tile, int& r, bool& valid) -> const XT* {
         r = tile * 32 + li;
         valid = r < R;
         const int rr = valid ? r : R - 1;
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
         const long img = idx ? (long)idx[b] : (long)b;
         return x + img * img_stride + (oy * G::S) * G::W + ox * G::S + half_off;
     };
-    auto stage_load = [&](VT (&buf)[NL], const float* base, int s) {
+    auto stage_load = [&](VT (&buf)[NL], const XT* base, int s) {
 #pragma unroll
         for (int i = 0; i < NL; ++i) buf[i] = *reinterpret_cast<const VU*>(base + G::off0(s * NL + i));
         __builtin_amdgcn_sched_barrier(0);     // the compiler otherwise sinks these loads below the MFMAs they overlap
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
     VT buf[2][NL];
     int r; bool valid;
     int mg = item % MG;
-    const float* base = lane_base(item / MG, r, valid);
+    const XT* base = lane_base(item / MG, r, valid);
     stage_load(buf[0], base, 0);
     load_a(0, mg);
     load_a(1, mg);
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
         const bool has_next = kround + 1 < my_items;
         const int next_item = has_next ? item_of(kround + 1) : item;
         int r_next = 0; bool valid_next = false;
-        const float* base_next = base;
+        const XT* base_next = base;
         const int mg_next = has_next ? next_item % MG : mg;
         if (has_next) base_next = lane_base(next_item / MG, r_next, valid_next);
 
@@ -411,7 +422,7 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
                 for (int t = 0; t < G::E; ++t)
 #pragma unroll
                     for (int a = 0; a < TMW; ++a)
-                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[q & 3][a][t], buf[s & 1][i][t], acc[a], 0, 0, 0);
+                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[q & 3][a][t], sw_tap(buf[s & 1][i], t), acc[a], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -423,11 +434,11 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const float* __restrict_
 
 int sw_num_cus();
 
-template <class G, class Epi>
-int launch_conv_sw(const float* x, const int64_t* idx, const float* wimg, const Epi& epi, int R, hipStream_t stream) {
+template <class G, class Epi, class XT = float>
+int launch_conv_sw(const XT* x, const int64_t* idx, const float* wimg, const Epi& epi, int R, hipStream_t stream) {
     const int ntiles = cdiv(R, 32);
     constexpr int smem_bytes = (int)G::lds_bytes();
-    auto kern = conv_sw_kernel<G, Epi>;
+    auto kern = conv_sw_kernel<G, Epi, XT>;
     if (smem_bytes > 48 * 1024) {
         static bool attr_set = false;      // per instantiation
         if (!attr_set) {

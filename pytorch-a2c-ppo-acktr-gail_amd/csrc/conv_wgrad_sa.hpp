@@ -155,11 +155,18 @@ __global__ __launch_bounds__(64 * SA3_WAVES) void conv3_wgrad_sa_kernel(const fl
 constexpr int S1_C = 4, S1_H = 84, S1_OC = 32, S1_SP = 400, S1_KC = 256, S1_GROUPS = 10, S1_WAVES = 8;
 constexpr int S1_LDS_BYTES = S1_WAVES * 4 * 16 * 64 * 4;
 
-struct S1Block { f32x4 a, b[4]; };
+// XT = uint8_t (frames stored as bytes): the lane's 16 frame values of a block are ONE 16-byte
+// load instead of four, converted (exactly) where the MFMA consumes them; same products in the same order.
+template <class XT> struct S1Block { f32x4 a, b[4]; };
+template <> struct S1Block<uint8_t> { f32x4 a; u32x4 bq; };
+__device__ __forceinline__ float s1_b(const S1Block<float>& blk, int s, int q) { return blk.b[s][q]; }
+__device__ __forceinline__ float s1_b(const S1Block<uint8_t>& blk, int s, int q) { return (float)((blk.bq[s] >> (8 * q)) & 0xffu); }
 
-__global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+template <class XT>
+__global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const XT* __restrict__ x, const int64_t* __restrict__ idx,
                                                                        const float* __restrict__ dy, float* __restrict__ slabs,
                                                                        long slab_stride, int B, float scale) {
+    constexpr bool U8 = std::is_same<XT, uint8_t>::value;
     extern __shared__ __attribute__((aligned(16))) float s1_red[];
     // (wave index through readfirstlane: the compiler then keeps the reduction range, the image pointers and the gather
     //  index in scalar registers -- as lane values they made the loop a divergent one with a vector load of idx[b] and a
@@ -185,20 +192,25 @@ __global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const flo
         for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
     float bsum = 0.f;
 
-    S1Block ring[5];
-    auto ptrs = [&](int g, const float*& xb, const float*& dyb) {      // group g -> image b, row pair t (wave-uniform)
+    S1Block<XT> ring[5];
+    auto ptrs = [&](int g, const XT*& xb, const float*& dyb) {      // group g -> image b, row pair t (wave-uniform)
         const int b = g / S1_GROUPS, t = g - b * S1_GROUPS;
         const long img = idx ? idx[b] : (long)b;
         xb = x + img * (S1_C * S1_H * S1_H) + t * (8 * S1_H);
         dyb = dy + (long)b * (S1_OC * S1_SP) + t * 40;
     };
-    auto issue = [&](S1Block& blk, int j, const float* xb, const float* dyb) {
+    struct __attribute__((packed, aligned(4))) UQ { u32x4 v; };
+    auto issue = [&](S1Block<XT>& blk, int j, const XT* xb, const float* dyb) {
         blk.a = *reinterpret_cast<const f32x4*>(dyb + aoff[j]);
+        if constexpr (U8) blk.bq = reinterpret_cast<const UQ*>(xb + boff[j])->v;
+        else {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) blk.b[s] = *reinterpret_cast<const f32x4*>(xb + boff[j] + 4 * s);
+            for (int s = 0; s < 4; ++s) blk.b[s] = *reinterpret_cast<const f32x4*>(xb + boff[j] + 4 * s);
+        }
     };
     if (g0 < g1) {
-        const float *xb, *dyb;
+        const XT* xb;
+        const float* dyb;
         ptrs(g0, xb, dyb);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
@@ -206,13 +218,14 @@ __global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const flo
             __builtin_amdgcn_sched_barrier(0);
         }
         for (int g = g0; g < g1; ++g) {
-            const float *xn, *dyn;
+            const XT* xn;
+            const float* dyn;
             ptrs(g + 1 < g1 ? g + 1 : g1 - 1, xn, dyn);      // past the end: the last group again (never multiplied)
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
                 // one refill load behind every four MFMAs (a burst of five loads behind sixteen MFMAs left the matrix
                 // pipe idle while the wave sat in the address path's queue)
-                S1Block& blk = ring[j];
+                S1Block<XT>& blk = ring[j];
                 const f32x4 a = blk.a;
                 bsum += (a[0] + a[1]) + (a[2] + a[3]);
                 blk.a = *reinterpret_cast<const f32x4*>(dyn + aoff[j]);
@@ -220,8 +233,9 @@ __global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const flo
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], blk.b[s][q], acc[q], 0, 0, 0);
-                    blk.b[s] = *reinterpret_cast<const f32x4*>(xn + boff[j] + 4 * s);
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], s1_b(blk, s, q), acc[q], 0, 0, 0);
+                    if constexpr (!U8) blk.b[s] = *reinterpret_cast<const f32x4*>(xn + boff[j] + 4 * s);
+                    else if (s == 3) blk.bq = reinterpret_cast<const UQ*>(xn + boff[j])->v;
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }

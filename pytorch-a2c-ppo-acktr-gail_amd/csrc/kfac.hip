@@ -8,6 +8,7 @@
 //   * Kronecker-eigenbasis preconditioning (kfac.py:216-227) as four MFMA GEMMs with the damped division
 //     fused into the second one's epilogue;
 //   * KL clip (kfac.py:229-239) computed on the device (no host sync) feeding the SGD-momentum kernel.
+#include <type_traits>
 #include <rocsolver/rocsolver.h>
 
 #include <stdlib.h>
@@ -54,9 +55,10 @@ static int cov_a_conv_t(const float* x, const int64_t* idx, int B, int C, float 
 }
 
 // 8x8 stride-4 layer on 84x84x4 frames: stationary accumulators, one workgroup per CU (kfac_cov_sa.hpp)
-static int cov_a_conv1_sa(const float* x, const int64_t* idx, int B, float alpha, float* out, float* ws, long ws_floats,
-                          hipStream_t s) {
-    static const bool off = getenv("ACKTR_COV_A_TILE") != nullptr;          // tuning / comparison switch
+template <class XT>
+static int cov_a_conv1_sa(const XT* x, const int64_t* idx, int B, float alpha, float* out, float* ws, long ws_floats,
+                          hipStream_t s, bool any_batch = false) {
+    static const bool off = getenv("ACKTR_COV_A_TILE") != nullptr && !std::is_same<XT, uint8_t>::value;   // tuning switch
     hipDeviceProp_t prop;
     static int cus = 0;
     if (!cus) {
@@ -66,8 +68,9 @@ static int cov_a_conv1_sa(const float* x, const int64_t* idx, int B, float alpha
     }
     int ns = B * C1A_GROUPS / 10;                       // at least ten row-pair groups per workgroup
     if (ns > cus) ns = cus;
-    if (off || B < 64 || ns < 1 || ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * C1A_D * C1A_D) return -2;
-    hipLaunchKernelGGL(cov_a_conv1_sa_kernel, dim3(ns), dim3(256), 0, s, x, idx, ws, B);
+    if (ns < 1) ns = 1;
+    if (off || (B < 64 && !any_batch) || ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * C1A_D * C1A_D) return -2;
+    hipLaunchKernelGGL(cov_a_conv1_sa_kernel<XT>, dim3(ns), dim3(256), 0, s, x, idx, ws, B);
     ACKTR_LAUNCH_CHECK();
     int rc = launch_slab_reduce(out, ws, ns, (long)C1A_D * C1A_D, (long)C1A_D * C1A_D, alpha, 0, s);
     if (rc) return rc;
@@ -357,6 +360,16 @@ extern "C" long acktr_kfac_cov_workspace_bytes(int D, long R) {
     int ns = pick_slices(tiles, R, 1024);
     if (ns > 512) ns = 512;
     return (long)(ns + SLAB_GROUP_EXTRA) * D * D * (long)sizeof(float);
+}
+
+extern "C" int acktr_kfac_cov_a_conv1_u8(const uint8_t* x, const int64_t* gather_idx, int B, float alpha, float* out,
+                                         void* workspace, long workspace_bytes, void* stream) {
+    ACKTR_ARG(x && out && workspace, "kfac_cov_a_conv1_u8: null pointer");
+    ACKTR_ARG(B > 0 && ((uintptr_t)x & 3) == 0, "kfac_cov_a_conv1_u8: bad batch size or alignment");
+    const int rc = cov_a_conv1_sa<uint8_t>(x, gather_idx, B, alpha, out, (float*)workspace,
+                                           workspace_bytes / (long)sizeof(float), (hipStream_t)stream, true);
+    ACKTR_ARG(rc != -2, "kfac_cov_a_conv1_u8: workspace too small (acktr_kfac_cov_workspace_bytes(256, B * 400))");
+    return rc;
 }
 
 extern "C" int acktr_kfac_cov_a_conv_f32(const float* x, const int64_t* gather_idx, int B, int C, int H, int W,

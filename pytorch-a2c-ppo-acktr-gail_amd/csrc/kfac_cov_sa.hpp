@@ -18,13 +18,22 @@
 //     (r, c) with block(r) > block(c) from (c, r) (those slab elements are never written, and what the reduction summed
 //     there is overwritten).
 #pragma once
+#include <type_traits>
 #include "gemm_core.hpp"
 
 namespace acktr {
 
 constexpr int C1A_H = 84, C1A_C = 4, C1A_D = 256, C1A_GROUPS = 10;
 
-struct C1aBlock { f32x4 v[2][4]; };      // [channel half][position s of the lane's four]
+// [channel half][position s of the lane's four]; XT = uint8_t (frames stored as bytes): the four kx of a position are
+// one dword, a channel half's four positions ONE 16-byte load, converted exactly where the MFMA consumes them
+template <class XT> struct C1aBlock { f32x4 v[2][4]; };
+typedef unsigned int c1a_u32x4 __attribute__((ext_vector_type(4)));
+template <> struct C1aBlock<uint8_t> { c1a_u32x4 v[2]; };
+__device__ __forceinline__ float c1a_val(const C1aBlock<float>& b, int nh, int s, int q) { return b.v[nh][s][q]; }
+__device__ __forceinline__ float c1a_val(const C1aBlock<uint8_t>& b, int nh, int s, int q) {
+    return (float)((b.v[nh][s] >> (8 * q)) & 0xffu);
+}
 
 // k-th upper-triangle tile pair (i <= j over 8 blocks, row-major enumeration) of wave W: pair number 4k + W
 constexpr int c1a_pair(int W, int k, int which) {
@@ -50,10 +59,12 @@ __device__ __forceinline__ int c1a_tap(int blk, int li) {
     return (((2 * (blk >> 2) + (li >> 4)) * 8 + ((li >> 1) & 7)) * 8) + (li & 1) * 4 + (blk & 3);
 }
 
-template <int W>
-__device__ __forceinline__ void c1a_wave(const float* __restrict__ x, const int64_t* __restrict__ idx, float* __restrict__ slab,
+template <int W, class XT>
+__device__ __forceinline__ void c1a_wave(const XT* __restrict__ x, const int64_t* __restrict__ idx, float* __restrict__ slab,
                                          int g0, int g1, int li, int h) {
     constexpr C1aTab<W> tab{};
+    constexpr bool U8 = std::is_same<XT, uint8_t>::value;
+    struct __attribute__((packed, aligned(4))) UQ { c1a_u32x4 v; };
     int boff[2][5];
 #pragma unroll
     for (int nh = 0; nh < 2; ++nh)
@@ -67,36 +78,46 @@ __device__ __forceinline__ void c1a_wave(const float* __restrict__ x, const int6
     for (int k = 0; k < 9; ++k)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[k][i] = 0.f;
-    C1aBlock ring[5];
+    C1aBlock<XT> ring[5];
     auto ptr = [&](int g) {                      // group g -> image, row pair (wave-uniform)
         const int b = g / C1A_GROUPS, t = g - b * C1A_GROUPS;
         const long img = idx ? idx[b] : (long)b;
         return x + img * (C1A_C * C1A_H * C1A_H) + t * (8 * C1A_H);
     };
     if (g0 < g1) {
-        const float* xb = ptr(g0);
+        const XT* xb = ptr(g0);
 #pragma unroll
         for (int j = 0; j < 5; ++j) {
+            if constexpr (U8) {
 #pragma unroll
-            for (int s = 0; s < 4; ++s)
+                for (int nh = 0; nh < 2; ++nh) ring[j].v[nh] = reinterpret_cast<const UQ*>(xb + boff[nh][j])->v;
+            } else {
 #pragma unroll
-                for (int nh = 0; nh < 2; ++nh) ring[j].v[nh][s] = *reinterpret_cast<const f32x4*>(xb + boff[nh][j] + 4 * s);
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int nh = 0; nh < 2; ++nh) ring[j].v[nh][s] = *reinterpret_cast<const f32x4*>(xb + boff[nh][j] + 4 * s);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         for (int g = g0; g < g1; ++g) {
-            const float* xn = ptr(g + 1 < g1 ? g + 1 : g1 - 1);     // past the end: the last group again (never multiplied)
+            const XT* xn = ptr(g + 1 < g1 ? g + 1 : g1 - 1);     // past the end: the last group again (never multiplied)
 #pragma unroll
             for (int j = 0; j < 5; ++j) {
-                C1aBlock& blk = ring[j];
+                C1aBlock<XT>& blk = ring[j];
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
 #pragma unroll
                     for (int k = 0; k < 9; ++k) {
                         const int bi = tab.i[k], bj = tab.j[k];
-                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(blk.v[bi >> 2][s][bi & 3], blk.v[bj >> 2][s][bj & 3], acc[k], 0, 0, 0);
+                        acc[k] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1a_val(blk, bi >> 2, s, bi & 3), c1a_val(blk, bj >> 2, s, bj & 3), acc[k], 0, 0, 0);
                     }
+                    if constexpr (!U8) {
 #pragma unroll
-                    for (int nh = 0; nh < 2; ++nh) blk.v[nh][s] = *reinterpret_cast<const f32x4*>(xn + boff[nh][j] + 4 * s);
+                        for (int nh = 0; nh < 2; ++nh) blk.v[nh][s] = *reinterpret_cast<const f32x4*>(xn + boff[nh][j] + 4 * s);
+                    } else if (s == 3) {
+#pragma unroll
+                        for (int nh = 0; nh < 2; ++nh) blk.v[nh] = reinterpret_cast<const UQ*>(xn + boff[nh][j])->v;
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
@@ -115,17 +136,18 @@ __device__ __forceinline__ void c1a_wave(const float* __restrict__ x, const int6
 }
 
 // grid = slabs (one workgroup per CU), block = 4 waves
-__global__ __launch_bounds__(256) void cov_a_conv1_sa_kernel(const float* __restrict__ x, const int64_t* __restrict__ idx,
+template <class XT>
+__global__ __launch_bounds__(256) void cov_a_conv1_sa_kernel(const XT* __restrict__ x, const int64_t* __restrict__ idx,
                                                              float* __restrict__ slabs, int B) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, h = lane >> 5;
     const long G = (long)B * C1A_GROUPS;
     const int g0 = (int)(G * blockIdx.x / gridDim.x), g1 = (int)(G * (blockIdx.x + 1) / gridDim.x);
     float* slab = slabs + (long)blockIdx.x * (C1A_D * C1A_D);
-    if (wave == 0) c1a_wave<0>(x, idx, slab, g0, g1, li, h);
-    else if (wave == 1) c1a_wave<1>(x, idx, slab, g0, g1, li, h);
-    else if (wave == 2) c1a_wave<2>(x, idx, slab, g0, g1, li, h);
-    else c1a_wave<3>(x, idx, slab, g0, g1, li, h);
+    if (wave == 0) c1a_wave<0, XT>(x, idx, slab, g0, g1, li, h);
+    else if (wave == 1) c1a_wave<1, XT>(x, idx, slab, g0, g1, li, h);
+    else if (wave == 2) c1a_wave<2, XT>(x, idx, slab, g0, g1, li, h);
+    else c1a_wave<3, XT>(x, idx, slab, g0, g1, li, h);
 }
 
 // out[r][c] = out[c][r] wherever block(r) > block(c)

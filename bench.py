@@ -134,6 +134,7 @@ def side_metrics(device):
     from a2c_ppo_acktr import algo
     from a2c_ppo_acktr.model import Policy
     from a2c_ppo_acktr.storage import RolloutStorage
+    from a2c_ppo_acktr import ops
     out = {}
     # ---- A2C, B = 80
     T, N = 5, 16
@@ -217,6 +218,31 @@ def side_metrics(device):
                                       mfma_tflops=round(spu * FWD_BWD_FLOP_PER_SAMPLE / (med * 1e-3) / 1e12, 2),
                                       frac_of_f32_mfma_peak=round(spu * FWD_BWD_FLOP_PER_SAMPLE / (med * 1e-3) / 1e12
                                                                   / MFMA_F32_PEAK_TFLOPS, 4))
+    del rs, agent, pol, ro
+    torch.cuda.empty_cache()
+    # ---- the headline workload with the frames kept as bytes on the device (RolloutStorage(obs_dtype=torch.uint8), not
+    # the reference's float32 storage -- which is why it is a side metric): same kernels apart from conv1's loaders,
+    # bit-identical results (tests/test_u8_gpu.py), a quarter of the observation traffic
+    T, N = T_STEPS, PROCS_PER_GPU
+    ro = synth_rollouts(T, N, device, seed=1234)
+    ro['obs'] = ro['obs'].to(torch.uint8)
+    pol, agent = build_agent(device, seed=7)
+    rs = fill_storage(ro, device)
+    rs.compute_returns(ro['next_value'], True, 0.99, 0.95, True)
+    _timed_updates(agent, rs, 3, 900)
+    ms = _timed_updates(agent, rs, 10, 910)
+    med = statistics.median(ms)
+    spu = T * N * PPO_HP['ppo_epoch']
+    ops.profiler = {}
+    agent.update(rs)
+    k8 = {k: round(v['avg_ms'] * 1e3, 1) for k, v in ops.profile_summary().items() if k.startswith('conv8s4')}
+    ops.profiler = None
+    out['ppo_update_uint8_obs'] = dict(workload='PPO.update NatureCNN, 32 procs x 128 steps, frames stored as uint8 on the device '
+                                                '(minibatch 1024)',
+                                       ms_median=round(med, 3), samples_per_s=round(spu / (med * 1e-3), 1),
+                                       frac_of_f32_mfma_peak=round(spu * FWD_BWD_FLOP_PER_SAMPLE / (med * 1e-3) / 1e12
+                                                                   / MFMA_F32_PEAK_TFLOPS, 4),
+                                       conv1_us_by_hip_events=k8)
     del rs, agent, pol, ro
     torch.cuda.empty_cache()
     # ---- GAE scan (20 B per element: GAE + proper time limits): the stress size of configs[4], where the serial

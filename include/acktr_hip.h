@@ -219,6 +219,20 @@ typedef struct acktr_head_fin {
 int acktr_head_step_deferred_f32(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh,
                                  float* dfeat, float* dwh, float* dbh, int H, acktr_head_fin* pending, void* stream);
 
+/* The head step fed by the FC layer's split-K slabs instead of finished features (model.py:180 `Linear(32*7*7, 512)` +
+ * ReLU, then model.py:185,195 / distributions.py:69-73 as above): acktr_linear_fwd_slabs_f32 runs only the product
+ * x W^T into nslabs partial [B, OUT] slabs (slab stride B*OUT floats; *nslabs_out >= 1; workspace >=
+ * acktr_linear_fwd_slabs_workspace_bytes), and acktr_head_step_slabs_f32 forms features = relu(sum of the slabs in order +
+ * fc_bias) in the registers that feed its dot products.  The features are never written: only the head step consumes
+ * them on this path (the FC weight gradient reads dfeat and the FC input).  pending: nullable, as in
+ * acktr_head_step_deferred_f32.  No counterpart in the reference (one torch op per layer there). */
+long acktr_linear_fwd_slabs_workspace_bytes(int B, int IN, int OUT);
+int acktr_linear_fwd_slabs_f32(const float* x, const float* w, int B, int IN, int OUT, void* workspace,
+                               long workspace_bytes, int* nslabs_out, void* stream);
+int acktr_head_step_slabs_f32(const acktr_loss_args* args, const float* feat_slabs, int nslabs, long slab_stride,
+                              const float* fc_bias, const float* wh, const float* bh, float* dfeat, float* dwh, float* dbh,
+                              int H, acktr_head_fin* pending, void* stream);
+
 /* dist.log_probs(action) and dist.entropy() per sample -- model.py:74-77; entropy_mean (nullable, one float) receives
  * dist.entropy().mean() of model.py:77 (fixed summation order). */
 int acktr_dist_fwd_f32(int dist, const float* dist_in, long ld, const float* logstd, const void* actions, int B, int A,

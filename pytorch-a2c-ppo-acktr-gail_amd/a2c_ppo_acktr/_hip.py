@@ -117,6 +117,10 @@ _PROTOS = {
     'acktr_gemm_f32': (c_i, [c_p, c_l, c_l, c_p, c_l, c_l, c_p, c_l, c_i, c_i, c_i, c_f, c_i, c_p]),
     'acktr_policy_loss_workspace_bytes': (c_l, [c_i, c_i]),
     'acktr_policy_loss_f32': (c_i, [ctypes.POINTER(LossArgs), c_p]),
+    'acktr_linear_fwd_slabs_workspace_bytes': (c_l, [c_i, c_i, c_i]),
+    'acktr_linear_fwd_slabs_f32': (c_i, [c_p, c_p, c_i, c_i, c_i, c_p, c_l, ctypes.POINTER(ctypes.c_int), c_p]),
+    'acktr_head_step_slabs_f32': (c_i, [ctypes.POINTER(LossArgs), c_p, c_i, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_i,
+                                        ctypes.POINTER(HeadFin), c_p]),
     'acktr_head_step_supported': (c_i, [c_i, c_i, c_i, c_i]),
     'acktr_head_step_workspace_bytes': (c_l, [c_i, c_i, c_i]),
     'acktr_head_step_f32': (c_i, [ctypes.POINTER(LossArgs), c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p]),

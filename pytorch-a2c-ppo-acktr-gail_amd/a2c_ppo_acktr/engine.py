@@ -62,6 +62,20 @@ class Acts(object):
 
     def __init__(self, cnn):
         self.cnn = cnn
+        self._feat = None
+        self._feat_fn = None
+
+    # FC features: materialised on demand when the forward left them as split-K slabs for the fused head step
+    # (forward(head=False), FOLD_FC_SLABS) -- tests and diagnostics read them, the update path never does
+    @property
+    def feat(self):
+        if self._feat is None and self._feat_fn is not None:
+            self._feat = self._feat_fn()
+        return self._feat
+
+    @feat.setter
+    def feat(self, v):
+        self._feat = v
 
     def value(self):
         return self.head[:, 0:1] if self.cnn else self.v
@@ -233,6 +247,13 @@ def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True
         a.y2 = ops.conv2d_fwd(a.y1, L['conv2'][0], L['conv2'][1].view(-1), 2, packed=pk.get('f2'))
         a.y3 = ops.conv2d_fwd(a.y2, L['conv3'][0], L['conv3'][1].view(-1), 1, packed=pk.get('f3'))
         a.flat3 = a.y3.view(a.y3.shape[0], -1)
+        if not head and not rec and FOLD_FC_SLABS:
+            # the fused head step is the features' only consumer on this path: it takes the FC product's split-K slabs
+            # and forms relu(sum + bias) itself (csrc/head_fused.hip) -- no slab-reduction launch, no feature matrix
+            a.head_in = None
+            a.feat_slabs = ops.linear_fwd_slabs(a.flat3, L['fc'][0]) + (L['fc'][1].view(-1),)
+            a._feat_fn = lambda: ops.linear_fwd(a.flat3, L['fc'][0], L['fc'][1].view(-1), 'relu')
+            return a
         a.feat = ops.linear_fwd(a.flat3, L['fc'][0], L['fc'][1].view(-1), 'relu')
         a.head_in = gru_forward(policy, a, a.feat, rnn_hxs, masks) if rec else a.feat
         if head:
@@ -418,6 +439,7 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
 # fused head + loss + head backward of the NatureCNN / Categorical path (csrc/head_fused.hip)
 # ----------------------------------------------------------------------------------------------
 FUSED_HEAD = os.environ.get('ACKTR_FUSED_HEAD', '1') != '0'
+FOLD_FC_SLABS = os.environ.get('ACKTR_FOLD_FC_SLABS', '1') != '0'      # comparison switch
 
 
 def head_step_ok(policy, B):
@@ -437,9 +459,13 @@ def head_step(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, o
     defer_finalize: the slab sums behind the head gradients and the loss are left pending and RETURNED (_hip.HeadFin)
     for the optimiser's norm launch to carry (`_FlatAdam.step(pending=...)`): until then gflat's head ranges and
     loss_acc are stale -- only for a caller that runs that optimiser step next on the same stream."""
-    feat = acts.head_in
+    slabs = getattr(acts, 'feat_slabs', None)        # (workspace, nslabs, slab stride in floats, FC bias): forward(head=False)
+    feat = acts.head_in if slabs is None else slabs[0]
     dev = feat.device
-    B, H = feat.shape
+    if slabs is None:
+        B, H = feat.shape
+    else:
+        B, H = acts.flat3.shape[0], slabs[3].numel()
     A = policy.dist.num_outputs
     L = _hip.lib()
     gflat = policy.flat_grads if gflat is None else gflat
@@ -464,7 +490,11 @@ def head_step(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None, o
     args.workspace, args.workspace_bytes = ws.data_ptr(), ws.numel()
     pending = _hip.HeadFin() if defer_finalize else None
     with ops._Timed('head%dx%d_step' % (H, 1 + A), 6.0 * B * H * (1 + A)):
-        if pending is not None:
+        if slabs is not None:
+            rc = L.acktr_head_step_slabs_f32(ctypes.byref(args), _hip.dev_ptr(slabs[0], torch.uint8), int(slabs[1]), int(slabs[2]),
+                                             p(slabs[3]), p(wh.detach()), p(bh.detach()), p(dfeat), p(gwh), p(gbh), H,
+                                             ctypes.byref(pending) if pending is not None else None, _hip.cur_stream(dev))
+        elif pending is not None:
             rc = L.acktr_head_step_deferred_f32(ctypes.byref(args), p(feat), p(wh.detach()), p(bh.detach()), p(dfeat),
                                                 p(gwh), p(gbh), H, ctypes.byref(pending), _hip.cur_stream(dev))
         else:

@@ -249,6 +249,22 @@ def linear_fwd(x, w, bias, act=None, out=None):
     return out
 
 
+def linear_fwd_slabs(x, w):
+    """x w^T as split-K slabs (no bias, no activation, no reduction): returns (workspace, nslabs, slab stride in floats).
+    The slabs live in a scratch buffer of their own tag: valid until the next call on this device."""
+    B, IN = x.shape
+    OUT = w.shape[0]
+    assert w.shape[1] == IN
+    L = _hip.lib()
+    ws = workspace(x.device, L.acktr_linear_fwd_slabs_workspace_bytes(B, IN, OUT), tag='fcslabs')
+    ns = ctypes.c_int(0)
+    with _Timed('linear%dx%d_fwd' % (IN, OUT), 2.0 * B * IN * OUT):
+        rc = L.acktr_linear_fwd_slabs_f32(_p(x, 'x'), _p(w, 'w'), B, IN, OUT, _p(ws, 'workspace', torch.uint8), ws.numel(),
+                                          ctypes.byref(ns), _hip.cur_stream(x.device))
+    _hip.check(rc, 'acktr_linear_fwd_slabs_f32')
+    return ws, ns.value, B * OUT
+
+
 def linear_dgrad(dy, w, gate_src=None, gate=None, out=None, accumulate=False, padded_out=None, planes=None):
     """padded_out [B, C, OH+2p, OW+2p] with planes=(C, OH, OW): dx is also written there as zero-padded planes
     (interior only) -- the dY layout of the conv dgrad that follows an FC layer."""

@@ -257,11 +257,24 @@ int sw_num_cus() {
 // (last parameter: threads per workgroup.  3-4 waves per SIMD were measured no faster than 2 except for the conv3
 //  dgrad: the kernels are paced by the MFMA pipe and the L1, and the smaller prefetch stages that fit the tighter
 //  register budget cost more than the extra waves hide)
-using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, 8, HM_KX, 512, false>;
-using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, 8, HM_KY, 512>;
-using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, 12, HM_CH, 512>;
+// (stage depths NL: compile-time switches for same-box A/B builds, tools/ab_update.py)
+#ifndef ACKTR_NL_F1
+#define ACKTR_NL_F1 16     // (8: 68.8 us, 16: 66.9 us at minibatch 1024, same-box A/B; the other layers lose with deeper stages)
+#endif
+#ifndef ACKTR_NL_F2
+#define ACKTR_NL_F2 8
+#endif
+#ifndef ACKTR_NL_F3
+#define ACKTR_NL_F3 12
+#endif
+#ifndef ACKTR_NL_D2
+#define ACKTR_NL_D2 8
+#endif
+using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, ACKTR_NL_F1, HM_KX, 512, false>;
+using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, ACKTR_NL_F2, HM_KY, 512>;
+using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, ACKTR_NL_F3, HM_CH, 512>;
 using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 8, HM_CH, 768>;     // padded 7x7 dY, flipped 3x3 kernel (stages of 8: room for the prefetched gate in 168 registers)
-using SwD2 = SwGeom<2, 2, 1, 11, 11, 64, 4, 2, 8, HM_CH, 512>;     // padded 9x9 dY, four 2x2 phase kernels stacked along M
+using SwD2 = SwGeom<2, 2, 1, 11, 11, 64, 4, 2, ACKTR_NL_D2, HM_CH, 512>;     // padded 9x9 dY, four 2x2 phase kernels stacked along M
 
 static long sw_fwd_image_bytes(int geom, int C, int OC) {
     if (geom == GEOM_8S4 && SwF1::ok(C, OC)) return SwF1::lds_bytes();

@@ -51,7 +51,11 @@ template <int ALGO>
 __global__ __launch_bounds__(256) void head_step_kernel(acktr_loss_args a, const float* __restrict__ feat,
                                                         const float* __restrict__ wh, const float* __restrict__ bh,
                                                         float* __restrict__ dfeat, float* __restrict__ slabs,
-                                                        long slab_stride, int OUT) {
+                                                        long slab_stride, int OUT, int nfs, long fs_stride,
+                                                        const float* __restrict__ fbias) {
+    // nfs > 0: `feat` is not the finished feature matrix but the FC layer's nfs split-K slabs (acktr_linear_fwd_slabs_f32):
+    // the features are relu(sum of the slabs in order + fbias), formed right here in the registers that feed the dot
+    // products -- the FC forward's slab-reduction launch (4.7 us of the 557 us step) and its 2 MB round trip disappear.
     __shared__ float red[HS_WAVES - 1][HS_OUT][HS_H];          // 48 KB: waves 1..3 hand their dW partials to wave 0
     __shared__ float tail[HS_WAVES][HS_TAIL];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,6 +86,30 @@ __global__ __launch_bounds__(256) void head_step_kernel(acktr_loss_args a, const
             const int rr = r0 + r < B ? r0 + r : B - 1;
 #pragma unroll
             for (int q = 0; q < 2; ++q) x[r][q] = *reinterpret_cast<const hf4*>(feat + (long)rr * HS_H + q * 256 + 4 * lane);
+        }
+        if (nfs > 0) {                                          // (wave-uniform)
+            for (int sl = 1; sl < nfs; ++sl) {
+                hf4 y[HS_RPW][2];
+#pragma unroll
+                for (int r = 0; r < HS_RPW; ++r) {
+                    const int rr = r0 + r < B ? r0 + r : B - 1;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        y[r][q] = *reinterpret_cast<const hf4*>(feat + (long)sl * fs_stride + (long)rr * HS_H + q * 256 + 4 * lane);
+                }
+#pragma unroll
+                for (int r = 0; r < HS_RPW; ++r)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) x[r][q] += y[r][q];
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const hf4 fb = *reinterpret_cast<const hf4*>(fbias + q * 256 + 4 * lane);
+#pragma unroll
+                for (int r = 0; r < HS_RPW; ++r)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { const float v = x[r][q][j] + fb[j]; x[r][q][j] = v > 0.f ? v : 0.f; }
+            }
         }
         const long act64 = ((const int64_t*)a.actions)[src_l];
         const int act_l = (act64 >= 0 && act64 < A) ? (int)act64 : -1;
@@ -223,7 +251,8 @@ extern "C" long acktr_head_step_workspace_bytes(int B, int H, int A) {
 }
 
 static int head_step_launch(const acktr_loss_args* args, const float* feat, const float* wh, const float* bh, float* dfeat,
-                            float* dwh, float* dbh, int H, void* stream, acktr_head_fin* defer) {
+                            float* dwh, float* dbh, int H, void* stream, acktr_head_fin* defer, int nfs = 0,
+                            long fs_stride = 0, const float* fbias = nullptr) {
     ACKTR_ARG(args, "head_step: null args");
     const acktr_loss_args& a = *args;
     ACKTR_ARG(acktr_head_step_supported(a.B, H, a.A, a.dist), "head_step: unsupported shape B=%d H=%d A=%d dist=%d", a.B, H,
@@ -241,9 +270,11 @@ static int head_step_launch(const acktr_loss_args* args, const float* feat, cons
     const int OUT = 1 + a.A, nb = head_slabs(a.B);
     const long stride = (long)OUT * H + HS_TAIL;
     float* slabs = (float*)a.workspace;
-    if (a.algo == 0) hipLaunchKernelGGL((head_step_kernel<0>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT);
-    else if (a.algo == 1) hipLaunchKernelGGL((head_step_kernel<1>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT);
-    else hipLaunchKernelGGL((head_step_kernel<2>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT);
+    ACKTR_ARG(nfs == 0 || (nfs >= 1 && nfs <= 16 && fbias && fs_stride >= (long)a.B * H && fs_stride % 4 == 0 &&
+                           ((uintptr_t)fbias & 15) == 0), "head_step: bad feature-slab arguments");
+    if (a.algo == 0) hipLaunchKernelGGL((head_step_kernel<0>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT, nfs, fs_stride, fbias);
+    else if (a.algo == 1) hipLaunchKernelGGL((head_step_kernel<1>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT, nfs, fs_stride, fbias);
+    else hipLaunchKernelGGL((head_step_kernel<2>), dim3(nb), dim3(256), 0, s, a, feat, wh, bh, dfeat, slabs, stride, OUT, nfs, fs_stride, fbias);
     ACKTR_LAUNCH_CHECK();
     acktr_head_fin f;
     f.slabs = slabs; f.nb = nb; f.stride = stride; f.n4 = (int)(stride / 4); f.nw = OUT * H; f.OUT = OUT;
@@ -264,4 +295,12 @@ extern "C" int acktr_head_step_deferred_f32(const acktr_loss_args* args, const f
                                             void* stream) {
     ACKTR_ARG(pending && dbh, "head_step_deferred: null pointer");
     return head_step_launch(args, feat, wh, bh, dfeat, dwh, dbh, H, stream, pending);
+}
+
+extern "C" int acktr_head_step_slabs_f32(const acktr_loss_args* args, const float* feat_slabs, int nslabs, long slab_stride,
+                                         const float* fc_bias, const float* wh, const float* bh, float* dfeat, float* dwh,
+                                         float* dbh, int H, acktr_head_fin* pending, void* stream) {
+    ACKTR_ARG(nslabs >= 1, "head_step_slabs: nslabs must be >= 1");
+    ACKTR_ARG(!pending || dbh, "head_step_slabs: a deferred finalize needs dbh");
+    return head_step_launch(args, feat_slabs, wh, bh, dfeat, dwh, dbh, H, stream, pending, nslabs, slab_stride, fc_bias);
 }

@@ -583,6 +583,25 @@ extern "C" int acktr_linear_fwd_f32(const float* x, const float* w, const float*
     return gemm_rowmajor(x, IN, 1, w, IN, 1, e, B, OUT, IN, 1, s);
 }
 
+extern "C" long acktr_linear_fwd_slabs_workspace_bytes(int B, int IN, int OUT) {
+    const int ns = fwd_slices(B, IN, OUT, 1L << 40);
+    return (long)(ns + SLAB_GROUP_EXTRA) * B * OUT * (long)sizeof(float);
+}
+
+extern "C" int acktr_linear_fwd_slabs_f32(const float* x, const float* w, int B, int IN, int OUT, void* workspace,
+                                          long workspace_bytes, int* nslabs_out, void* stream) {
+    ACKTR_ARG(x && w && workspace && nslabs_out, "linear_fwd_slabs: null pointer");
+    ACKTR_ARG(B > 0 && IN > 0 && OUT > 0, "linear_fwd_slabs: bad sizes B=%d IN=%d OUT=%d", B, IN, OUT);
+    ACKTR_ARG(((uintptr_t)workspace & 15) == 0 && workspace_bytes >= (long)B * OUT * (long)sizeof(float),
+              "linear_fwd_slabs: workspace must be 16-byte aligned and hold at least one [B, OUT] slab");
+    float* ws = (float*)workspace;
+    const int ns = fwd_slices(B, IN, OUT, workspace_bytes / (long)sizeof(float) + (long)SLAB_GROUP_EXTRA * B * OUT);
+    RowMajorEpi e = row_major_epi(ws, B, OUT, OUT);
+    e.slab_stride = (long)B * OUT;
+    *nslabs_out = ns;
+    return gemm_rowmajor(x, IN, 1, w, IN, 1, e, B, OUT, IN, ns, (hipStream_t)stream);
+}
+
 extern "C" int acktr_linear_dgrad_f32(const float* dy, const float* w, const float* gate_src, int gate, float* dx,
                                       int B, int IN, int OUT, int accumulate, void* stream) {
     return acktr_linear_dgrad_ex_f32(dy, w, gate_src, gate, dx, B, IN, OUT, accumulate, nullptr, 0, 0, 0, 0, stream);

@@ -402,6 +402,41 @@ def test_head_step_matches_layer_path(B, A, algo_id, gather):
     assert np.array_equal(out[1][2] == 0, out[0][2] == 0) or (out[1][2] != 0).sum() > 0
 
 
+@pytest.mark.parametrize('B', [3, 80, 1024])
+def test_head_step_from_fc_slabs_matches_feature_path(B):
+    """forward(head=False) leaves the FC product as split-K slabs and the fused head step forms relu(sum + bias) itself
+    (engine.FOLD_FC_SLABS) -- against the same step on materialised features: head rows, losses and every gradient."""
+    from a2c_ppo_acktr import engine
+    from a2c_ppo_acktr.model import Policy
+    torch.manual_seed(23)
+    pol = Policy((4, 84, 84), Discrete(6))
+    pol.to('cuda')
+    g = torch.Generator(device='cuda').manual_seed(B)
+    obs = torch.randint(0, 256, (B, 4, 84, 84), device='cuda', generator=g).float()
+    act = torch.randint(0, 6, (B,), device='cuda', generator=g)
+    olp = 0.1 * torch.randn(B, device='cuda', generator=g) - 1.7
+    ov, ret, adv = (torch.randn(B, device='cuda', generator=g) for _ in range(3))
+    res = []
+    saved = engine.FOLD_FC_SLABS
+    try:
+        for fold in (True, False):
+            engine.FOLD_FC_SLABS = fold
+            gflat = torch.zeros_like(pol.flat_params)
+            acc = torch.zeros(3, device='cuda')
+            with torch.no_grad():
+                acts = engine.forward(pol, obs, head=False)
+                assert (getattr(acts, 'feat_slabs', None) is not None) == fold
+                engine.head_step(pol, acts, engine.ALGO_PPO, act, acc, 1.0 / B, old_logp=olp, old_values=ov, returns=ret,
+                                 adv=adv, clip=0.1, value_coef=0.5, entropy_coef=0.01, gflat=gflat)
+                engine.backward(pol, acts, gflat)
+            res.append((acts.head.clone(), acc.clone(), gflat.clone(), acts.feat.clone()))
+    finally:
+        engine.FOLD_FC_SLABS = saved
+    for a, b, what in zip(res[0], res[1], ('head', 'losses', 'gradients', 'features (materialised on demand)')):
+        err = float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+        assert err < 2e-6, (what, err)
+
+
 @pytest.mark.parametrize('B', [5, 96])
 def test_folded_dgrad_padding_is_bit_identical(B):
     """The zero-padded dY copies written by the producers' epilogues (FC dgrad -> conv3 dgrad -> conv2 dgrad,

@@ -97,8 +97,9 @@ typedef struct acktr_slab_fin {
     float* dst; const float* slabs; int nslabs; long n4; long stride; float scale;
 } acktr_slab_fin;
 /* The same weight gradient with its final slab sum left PENDING when the layer runs the stationary-accumulator kernel
- * whose slabs one launch can sum and db directly follows dw (the policy's conv1 at minibatches >= 256): `*pending`
- * then describes it for acktr_clip_adam_dev_head_f32 and dw / db are NOT complete until that call; otherwise the call
+ * whose slabs one launch can sum and db directly follows dw (the policy's three conv layers at minibatches >= 256):
+ * `*pending` then describes it for acktr_clip_adam_dev_head_f32 or acktr_conv2d_dgrad_carry_f32 and dw / db are NOT
+ * complete until that call; otherwise the call
  * completes as acktr_conv2d_wgrad_f32 does and pending->dst is NULL.  No counterpart in the reference. */
 int acktr_conv2d_wgrad_deferred_f32(const float* x, const int64_t* gather_idx, const float* dy, float* dw, float* db,
                                     int B, int C, int H, int W, int OC, int KH, int KW, int S, float in_scale,
@@ -123,6 +124,15 @@ long acktr_conv2d_dgrad_padded_dy_offset_bytes(int C, int H, int W, int OC, int 
 int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
                               int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, int flags,
                               float* dx_padded, int pad, void* stream);
+/* acktr_conv2d_dgrad_ex_f32 with a PENDING weight-gradient slab sum of the launch before it riding along (`carry`,
+ * nullable; as left by acktr_conv2d_wgrad_deferred_f32): extra workgroups of the stationary-weight launch sum the slabs
+ * into carry->dst while the last, partial round of the input gradient's work items leaves most CUs idle -- one
+ * dependent launch fewer per layer and step.  carry->dst is complete when this call's stream work is.  Shapes off the
+ * stationary path run the sum as a launch of its own first.  Launch scheduling only; no counterpart in the reference. */
+int acktr_conv2d_dgrad_carry_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H,
+                                 int W, int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, int flags,
+                                 float* dx_padded, int pad, const acktr_slab_fin* carry, void* stream);
+
 
 /* Re-ordered weights of up to 8 conv layers in ONE launch (no counterpart call in the reference: it is the weight
  * preparation the forward / dgrad entry points above otherwise launch themselves, model.py:176-179).  Each job names a

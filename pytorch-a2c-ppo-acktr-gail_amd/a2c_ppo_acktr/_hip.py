@@ -107,6 +107,7 @@ _PROTOS = {
     'acktr_conv2d_dgrad_f32': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_l, c_i, c_p]),
     'acktr_conv2d_dgrad_padded_dy_offset_bytes': (c_l, [c_i] * 7),
     'acktr_conv2d_dgrad_ex_f32': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_l, c_i, c_p, c_i, c_p]),
+    'acktr_conv2d_dgrad_carry_f32': (c_i, [c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_p, c_l, c_i, c_p, c_i, ctypes.POINTER(SlabFin), c_p]),
     'acktr_linear_dgrad_ex_f32': (c_i, [c_p, c_p, c_p, c_i, c_p, c_i, c_i, c_i, c_i, c_p, c_i, c_i, c_i, c_i, c_p]),
     'acktr_conv2d_pack_weights_f32': (c_i, [c_p, c_i, c_p]),
     'acktr_linear_fwd_workspace_bytes': (c_l, [c_i, c_i, c_i]),

@@ -350,20 +350,26 @@ def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None, defer_last
             acts.pd2 = ops.padded_dy_view(acts.packs.get('d2'), B3, w2, 2, 20) if FOLD_PAD else None
             dy3 = ops.linear_dgrad(dfeat, L['fc'][0], gate_src=acts.flat3, gate='relu', padded_out=acts.pd3,
                                    planes=tuple(acts.y3.shape[1:])).view_as(acts.y3)
+            # the slab sums of the conv3 / conv2 weight gradients ride in the NEXT launch (that layer's input gradient) as
+            # extra workgroups -- not across a phase boundary, where a data-parallel caller all-reduces in between
+            carry3 = _hip.SlabFin() if (wgrad and phase is None and CARRY_SLABS) else None
             if wgrad:
-                ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1))
+                ops.conv2d_wgrad(acts.y2, dy3, tuple(w3.shape), 1, gv(w3), gv(L['conv3'][1]).view(-1), pending=carry3)
             if phase == 1:
                 acts.dfeat, acts.dy3 = dfeat, dy3
                 return
         else:
             dfeat, dy3 = acts.dfeat, acts.dy3
+            carry3 = None
         pd3 = acts.pd3
         pd2 = acts.pd2 if pd3 is not None else None           # (conv3 dgrad off the stationary path: nobody fills pd2)
         dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1, packed=acts.packs.get('d3'), dy_prepadded=pd3 is not None,
-                               padded_out=pd2)
+                               padded_out=pd2, carry=carry3)
+        carry2 = _hip.SlabFin() if (wgrad and CARRY_SLABS) else None
         if wgrad:
-            ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1))
-        dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2, packed=acts.packs.get('d2'), dy_prepadded=pd2 is not None)
+            ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1), pending=carry2)
+        dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2, packed=acts.packs.get('d2'), dy_prepadded=pd2 is not None,
+                               carry=carry2)
         if wgrad:
             ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1),
                              in_scale=1.0 / 255.0, gather_idx=acts.idx, pending=defer_last)
@@ -440,6 +446,7 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
 # ----------------------------------------------------------------------------------------------
 FUSED_HEAD = os.environ.get('ACKTR_FUSED_HEAD', '1') != '0'
 FOLD_FC_SLABS = os.environ.get('ACKTR_FOLD_FC_SLABS', '1') != '0'      # comparison switch
+CARRY_SLABS = os.environ.get('ACKTR_CARRY_SLABS', '1') != '0'          # comparison switch
 
 
 def head_step_ok(policy, B):

@@ -202,10 +202,11 @@ def padded_dy_view(packed, B, w, stride, in_hw):
     return packed[off:off + 4 * n].view(f32).view(B, OC, 11, 11)
 
 
-def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None, dy_prepadded=False, padded_out=None):
+def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None, dy_prepadded=False, padded_out=None, carry=None):
     """dx = conv_transpose(dy, w) * (x_act > 0); x_act [B,C,H,W] is the (post-ReLU) input of the layer.
     dy_prepadded: `packed` already holds this dY zero-padded (see padded_dy_view); padded_out [B,C,H+2p,W+2p]: dx is
-    also written there, interior only."""
+    also written there, interior only.  carry (a _hip.SlabFin left pending by conv2d_wgrad(pending=...)): that weight
+    gradient's slab sum rides in this launch (acktr_conv2d_dgrad_carry_f32)."""
     OC, C, KH, KW = w.shape
     B, _, OH, OW = dy.shape
     H, W = (OH - 1) * stride + KH, (OW - 1) * stride + KW
@@ -221,11 +222,13 @@ def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None, dy_prepadded=False
     ws = packed if packed is not None else \
         workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride), tag='dgrad')
     with _Timed('conv%ds%d_dgrad' % (KH, stride), 2.0 * dy.numel() * C * KH * KW):
-        rc = L.acktr_conv2d_dgrad_ex_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
-                                         B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),
-                                         (1 if packed is not None else 0) | (2 if dy_prepadded else 0),
-                                         _p(padded_out, 'dx_padded'), pad, _hip.cur_stream(dy.device))
-    _hip.check(rc, 'acktr_conv2d_dgrad_ex_f32')
+        rc = L.acktr_conv2d_dgrad_carry_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
+                                            B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),
+                                            (1 if packed is not None else 0) | (2 if dy_prepadded else 0),
+                                            _p(padded_out, 'dx_padded'), pad,
+                                            ctypes.byref(carry) if (carry is not None and carry.dst) else None,
+                                            _hip.cur_stream(dy.device))
+    _hip.check(rc, 'acktr_conv2d_dgrad_carry_f32')
     return out
 
 

@@ -112,13 +112,18 @@ static int sa_wgrad_slabs(int B) {
     return cdiv(B, per);
 }
 static int conv3_wgrad_sa(const float* x, const float* dy, float* dw, float* db, int B, float scale, float* ws,
-                          long ws_floats, hipStream_t s) {
+                          long ws_floats, hipStream_t s, acktr_slab_fin* defer = nullptr) {
     constexpr int C = 64, KC = C * SA_KK;
     const long wk = (long)SA_OC * KC, slab = wk + SA_OC;
     const int per = cdiv(B, sw_num_cus()), ns = cdiv(B, per);
     if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
     hipLaunchKernelGGL((conv3_wgrad_sa_kernel<C>), dim3(ns), dim3(64 * SA3_WAVES), 0, s, x, dy, ws, slab, B, per, scale);
     ACKTR_LAUNCH_CHECK();
+    if (defer && db == dw + wk && ns >= 16 && (((uintptr_t)dw | (uintptr_t)ws) & 15) == 0) {
+        defer->dst = dw; defer->slabs = ws; defer->nslabs = ns; defer->n4 = (wk + SA_OC) / 4; defer->stride = slab;
+        defer->scale = 1.f;
+        return 0;
+    }
     if (db == dw + wk) return launch_slab_reduce(dw, ws, ns, wk + SA_OC, slab, 1.f, 0, s);
     int rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
     if (rc || !db) return rc;
@@ -172,12 +177,17 @@ static int sa2_wgrad_slabs(int B) {
     return by_work < cus ? (by_work < 1 ? 1 : by_work) : cus;
 }
 static int conv2_wgrad_sa(const float* x, const float* dy, float* dw, float* db, int B, float scale, float* ws, long ws_floats,
-                          hipStream_t s) {
+                          hipStream_t s, acktr_slab_fin* defer = nullptr) {
     const long wk = (long)S2_OC * S2_KC, slab = wk + S2_OC;
     const int ns = sa2_wgrad_slabs(B);
     if (ws_floats < (long)(ns + SLAB_GROUP_EXTRA) * slab) return -2;     // caller falls back to the tile GEMM
     hipLaunchKernelGGL(conv2_wgrad_sa_kernel, dim3(ns), dim3(64 * S2_WAVES), 0, s, x, dy, ws, slab, B, scale);
     ACKTR_LAUNCH_CHECK();
+    if (defer && db == dw + wk && ns >= 16 && (((uintptr_t)dw | (uintptr_t)ws) & 15) == 0) {
+        defer->dst = dw; defer->slabs = ws; defer->nslabs = ns; defer->n4 = (wk + S2_OC) / 4; defer->stride = slab;
+        defer->scale = 1.f;
+        return 0;
+    }
     if (db == dw + wk) return launch_slab_reduce(dw, ws, ns, wk + S2_OC, slab, 1.f, 0, s);
     int rc = launch_slab_reduce(dw, ws, ns, wk, slab, 1.f, 0, s);
     if (rc || !db) return rc;
@@ -418,7 +428,7 @@ static int conv2d_wgrad_impl(const float* x, const int64_t* gather_idx, const fl
         if (rc != -2) return rc;
     }
     if (sa2_wgrad_ok(geom, C, OC, B, gather_idx)) {
-        const int rc = conv2_wgrad_sa(x, dy, dw, db, B, in_scale, ws, wf, s);
+        const int rc = conv2_wgrad_sa(x, dy, dw, db, B, in_scale, ws, wf, s, defer);
         if (rc != -2) return rc;
     }
     if (geom == GEOM_8S4) return WG(8, 8, 4, 84, 84);
@@ -426,7 +436,7 @@ static int conv2d_wgrad_impl(const float* x, const int64_t* gather_idx, const fl
     if (gather_idx) return WG(3, 3, 1, 9, 9);
 #undef WG
     if (sa_wgrad_ok(geom, C, OC, gather_idx) && (long)B * C * 81 * 4 < (1L << 31)) {   // 32-bit byte offsets
-        const int rc = conv3_wgrad_sa(x, dy, dw, db, B, in_scale, ws, wf, s);
+        const int rc = conv3_wgrad_sa(x, dy, dw, db, B, in_scale, ws, wf, s, defer);
         if (rc != -2) return rc;
     }
     if (OC <= 32) return conv_wgrad_pos_t<3, 3, 9, 9, 8, 32, 1, 4>(x, dy, dw, db, B, C, OC, in_scale, ws, wf, s);
@@ -521,6 +531,19 @@ extern "C" int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const flo
 extern "C" int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C,
                                          int H, int W, int OC, int KH, int KW, int S, void* workspace,
                                          long workspace_bytes, int flags, float* dx_padded, int pad, void* stream) {
+    return acktr_conv2d_dgrad_carry_f32(dy, w, x_act, dx, B, C, H, W, OC, KH, KW, S, workspace, workspace_bytes, flags,
+                                        dx_padded, pad, nullptr, stream);
+}
+
+static int run_carry_alone(const acktr_slab_fin* carry, hipStream_t s) {
+    if (!carry || !carry->dst) return 0;
+    return launch_slab_reduce(carry->dst, carry->slabs, carry->nslabs, 4 * carry->n4, carry->stride, carry->scale, 0, s);
+}
+
+extern "C" int acktr_conv2d_dgrad_carry_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C,
+                                            int H, int W, int OC, int KH, int KW, int S, void* workspace,
+                                            long workspace_bytes, int flags, float* dx_padded, int pad,
+                                            const acktr_slab_fin* carry, void* stream) {
     const int prepacked = flags & 1;
     const bool prepadded = (flags & 2) != 0;      // the zero-padded dY already sits in the workspace (a producer wrote it)
     ACKTR_ARG((dy || prepadded) && w && dx, "conv2d_dgrad: null pointer");
@@ -549,22 +572,23 @@ extern "C" int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const 
             if (rc) return rc;
             if (x_act) {
                 SwPhase2Epi<10, 10, 20, 20, true> epi{dx, x_act};
-                return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s);
+                return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s, carry);
             }
             SwPhase2Epi<10, 10, 20, 20, false> epi{dx, nullptr};
-            return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s);
+            return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s, carry);
         }
         if (!prepacked) rc = launch_sw_pack<SwD3>(w, img, C, 1, C, 1, s);
         if (rc) return rc;
         const int pw = W + 2 * pad;
         if (x_act) {
             SwGateEpi<81, true> epi{dx, x_act, C, dx_padded, W, pw, (H + 2 * pad) * pw, pad * pw + pad};
-            return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s);
+            return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s, carry);
         }
         SwGateEpi<81, false> epi{dx, nullptr, C, dx_padded, W, pw, (H + 2 * pad) * pw, pad * pw + pad};
-        return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s);
+        return launch_conv_sw<SwD3>(dyp, nullptr, img, epi, B * 81, s, carry);
     }
     ACKTR_ARG(!prepadded && !dx_padded, "conv2d_dgrad: padded operands need the stationary-weight path (this shape runs the tile GEMM)");
+    { const int rcc = run_carry_alone(carry, s); if (rcc) return rcc; }      // (no stationary launch to ride in)
 #define DG(KH_, KW_, S_, OH_, OW_)                                                                 \
     (C <= 32 ? conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 32, 1, 4>(dy, w, x_act, dx, B, C, OC, wp, s)   \
              : conv_dgrad_t<KH_, KW_, S_, OH_, OW_, 64, 2, 2>(dy, w, x_act, dx, B, C, OC, wp, s))

@@ -21,6 +21,7 @@
 // lane ends up holding horizontally adjacent dX pixels and stores them as one 8-byte write.
 #pragma once
 #include "gemm_core.hpp"
+#include "head_finalize.hpp"
 
 namespace acktr {
 
@@ -300,11 +301,25 @@ __device__ __forceinline__ float sw_tap(uint32_t v, int t) { return (float)((v >
 // ---------------------------------------------------------------------------------------------------
 // main kernel
 // ---------------------------------------------------------------------------------------------------
+// A pending slab sum of the PREVIOUS launch (a weight gradient whose workgroup slabs are written but not yet added up,
+// acktr_slab_fin) can ride in this launch: workgroups [gmain, gridDim.x) do nothing but that sum.  They are numbered
+// behind the one-per-CU main workgroups, so they start on the CUs whose main workgroup has run out of items -- the
+// last, partial round of work items leaves most CUs idle for an item's time -- and the sum's own launch (6 us as a
+// kernel of its own: a dependent launch, a ramp, 19-34 MB of slabs) disappears from the step.
+struct SwCarry { acktr_slab_fin fin; int nvb; };      // nvb: virtual 256-thread blocks of slab_finalize_block
+
 template <class G, class Epi, class XT = float>
 __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x,
                                                              const int64_t* __restrict__ idx,
                                                              const float* __restrict__ wimg, const Epi epi, int R,
-                                                             int ntiles) {
+                                                             int ntiles, int gmain, const SwCarry carry) {
+    if ((int)blockIdx.x >= gmain) {
+        constexpr int VPB = G::NT / 256;                     // virtual blocks per workgroup pass
+        const int ncw = gridDim.x - gmain;
+        for (int vb = ((int)blockIdx.x - gmain) * VPB + (threadIdx.x >> 8); vb < carry.nvb; vb += ncw * VPB)
+            (void)slab_finalize_block(carry.fin, vb);
+        return;
+    }
     using VT = typename SwRaw<XT, G::E>::type;
     using VU = typename SwRaw<XT, G::E>::utype;
     using AT = typename TapVec<G::EP>::type;
@@ -365,13 +380,13 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
     // would land on all waves of the first few CUs, whose SIMDs then run two items more than everybody else's (conv2
     // dgrad at minibatch 1024: 6400 items on 2048 waves -> 8 item-times on 32 CUs against 6 elsewhere; now 7 everywhere).
     const int nitems = ntiles * MG;
-    const int item_stride = gridDim.x * G::NWAVES;
+    const int item_stride = gmain * G::NWAVES;
     // (not BY_WG) workgroups are dispatched round-robin over the 8 XCDs: renumber them so that consecutive items run
     // on the same XCD and share its L2 (conv1 forward: 72.5 -> 71.1 us)
-    const int bx = (gridDim.x % 8 == 0) ? (blockIdx.x % 8) * (gridDim.x / 8) + blockIdx.x / 8 : blockIdx.x;
-    const int slot = G::BY_WG ? blockIdx.x * G::NWAVES + wave : bx + gridDim.x * wave;
+    const int bx = (gmain % 8 == 0) ? (blockIdx.x % 8) * (gmain / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int slot = G::BY_WG ? blockIdx.x * G::NWAVES + wave : bx + gmain * wave;
     const int full = nitems / item_stride, rem = nitems - full * item_stride;
-    const int tail_slot = wave * gridDim.x + blockIdx.x;
+    const int tail_slot = wave * gmain + blockIdx.x;
     const int my_items = full + (tail_slot < rem ? 1 : 0);
     if (my_items == 0) return;
     auto item_of = [&](int k) { return k < full ? k * item_stride + slot : full * item_stride + tail_slot; };
@@ -435,7 +450,9 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
 int sw_num_cus();
 
 template <class G, class Epi, class XT = float>
-int launch_conv_sw(const XT* x, const int64_t* idx, const float* wimg, const Epi& epi, int R, hipStream_t stream) {
+int launch_conv_sw(const XT* x, const int64_t* idx, const float* wimg, const Epi& epi, int R, hipStream_t stream,
+                   const acktr_slab_fin* carry = nullptr) {
+    static_assert(G::NT % 256 == 0, "carry workgroups run virtual 256-thread blocks");
     const int ntiles = cdiv(R, 32);
     constexpr int smem_bytes = (int)G::lds_bytes();
     auto kern = conv_sw_kernel<G, Epi, XT>;
@@ -457,7 +474,17 @@ int launch_conv_sw(const XT* x, const int64_t* idx, const float* wimg, const Epi
     long grid_l = (long)ntiles * G::MG;
     const int cus = sw_num_cus();
     const int grid = (int)(grid_l > cus ? cus : grid_l);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(G::NT), smem_bytes, stream, x, idx, wimg, epi, R, ntiles);
+    SwCarry cy;
+    cy.fin.dst = nullptr; cy.fin.slabs = nullptr; cy.fin.nslabs = 0; cy.fin.n4 = 0; cy.fin.stride = 0; cy.fin.scale = 1.f;
+    cy.nvb = 0;
+    int extra = 0;
+    if (carry && carry->dst) {
+        cy.fin = *carry;
+        cy.nvb = (int)((carry->n4 + 15) / 16);
+        extra = cdiv(cy.nvb, G::NT / 256);
+        if (extra > 128) extra = 128;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid + extra), dim3(G::NT), smem_bytes, stream, x, idx, wimg, epi, R, ntiles, grid, cy);
     ACKTR_LAUNCH_CHECK();
     return 0;
 }

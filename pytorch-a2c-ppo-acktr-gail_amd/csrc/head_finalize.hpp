@@ -43,7 +43,8 @@ __device__ __forceinline__ double head_finalize_block(const acktr_head_fin& f, i
 // sub+16, ..., four-step butterfly) for a pending weight-gradient sum; `block` plays blockIdx.x of a 256-thread workgroup.
 // Returns the sum of squares of what this thread wrote.
 __device__ __forceinline__ double slab_finalize_block(const acktr_slab_fin& f, int block) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = (threadIdx.x >> 6) & 3;      // (& 3: callers with more than 256 threads pass one
+                                                                           //  virtual 256-thread block per four waves)
     const long i = ((long)block * 4 + wave) * 4 + (lane & 3);
     const int sub = lane >> 2;
     hfin4 acc = hfin4{0.f, 0.f, 0.f, 0.f};

@@ -306,6 +306,19 @@ int acktr_clip_adam_dev_head_f32(float* params, float* grads, float* exp_avg, fl
                                  float max_grad_norm, const float* hyper_dev, int* step_dev,
                                  const acktr_head_fin* pending, const acktr_slab_fin* slab, void* workspace,
                                  void* stream);
+/* acktr_clip_adam_dev_head_f32 that also keeps the stationary conv kernels' weight IMAGES (the re-ordered copies
+ * acktr_conv2d_pack_weights_f32 writes) in step with the parameters: element i of params in [lo, hi) is additionally
+ * stored to base[t1[i - lo]] and base[t2[i - lo]] (float offsets; -1 = no slot) -- its slot in the forward image and in
+ * the input-gradient image of its layer.  The next forward then needs no pack launch (4 us of a 0.55 ms step).  map
+ * nullable (then identical to acktr_clip_adam_dev_head_f32).  No counterpart in the reference. */
+typedef struct acktr_pack_map {
+    long lo, hi; const int* t1; const int* t2; float* base;
+} acktr_pack_map;
+int acktr_clip_adam_dev_pack_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                 float max_grad_norm, const float* hyper_dev, int* step_dev,
+                                 const acktr_head_fin* pending, const acktr_slab_fin* slab, const acktr_pack_map* map,
+                                 void* workspace, void* stream);
+
 /* clip_grad_norm_ + optim.RMSprop.step -- algo/a2c_acktr.py:74-78 (torch/optim/rmsprop.py:316-339). */
 int acktr_clip_rmsprop_f32(float* params, float* grads, float* square_avg, long n, float max_grad_norm, float lr,
                            float alpha, float eps, float* total_norm_out, void* workspace, void* stream);

@@ -70,6 +70,11 @@ class SlabFin(ctypes.Structure):
     _fields_ = [('dst', c_p), ('slabs', c_p), ('nslabs', c_i), ('n4', c_l), ('stride', c_l), ('scale', c_f)]
 
 
+class PackMap(ctypes.Structure):
+    """struct acktr_pack_map (include/acktr_hip.h): where the optimiser also stores conv weights (weight-image slots)"""
+    _fields_ = [('lo', c_l), ('hi', c_l), ('t1', c_p), ('t2', c_p), ('base', c_p)]
+
+
 class PrecondJob(ctypes.Structure):
     """struct acktr_precond_job (include/acktr_hip.h)"""
     _fields_ = [('grad', c_p), ('qt_g', c_p), ('d_g', c_p), ('qt_a', c_p), ('d_a', c_p), ('tmp1', c_p), ('tmp2', c_p),
@@ -135,6 +140,8 @@ _PROTOS = {
     'acktr_clip_adam_dev_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, c_p, c_p]),
     'acktr_clip_adam_dev_head_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, ctypes.POINTER(HeadFin),
                                            ctypes.POINTER(SlabFin), c_p, c_p]),
+    'acktr_clip_adam_dev_pack_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_f, c_p, c_p, ctypes.POINTER(HeadFin),
+                                           ctypes.POINTER(SlabFin), ctypes.POINTER(PackMap), c_p, c_p]),
     'acktr_clip_rmsprop_f32': (c_i, [c_p, c_p, c_p, c_l, c_f, c_f, c_f, c_f, c_p, c_p, c_p]),
     'acktr_sgd_momentum_f32': (c_i, [c_p, c_p, c_p, c_p, c_l, c_p, c_f, c_f, c_i, c_p]),
     'acktr_kfac_cov_workspace_bytes': (c_l, [c_i, c_l]),

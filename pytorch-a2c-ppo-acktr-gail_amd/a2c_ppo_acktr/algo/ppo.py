@@ -53,24 +53,26 @@ class _FlatAdam(object):
         """Host-side refresh of the device hyper-parameters; call outside graph capture."""
         self._state()
 
-    def step(self, max_grad_norm=None, capturing=False, pending=None, slab=None):
+    def step(self, max_grad_norm=None, capturing=False, pending=None, slab=None, image_map=None):
         """clip_grad_norm_(max_grad_norm) (if given) + Adam step on the flat buffers.  `pending`: a head step's deferred
         finalize (engine.head_step(defer_finalize=True)), `slab`: the last weight gradient's deferred slab sum
-        (engine.backward(defer_last=...)); both are carried by the norm launch."""
+        (engine.backward(defer_last=...)); both are carried by the norm launch.  `image_map` (engine.refresh_conv_images):
+        the new conv weights are also stored to their slots in the stationary kernels' weight images."""
         if not capturing:
             self._state()
         self.step_count += 1
         flat, gflat = self.policy.flat_params, self.policy.flat_grads
         L = _hip.lib()
         ws = ops.workspace(flat.device, L.acktr_optim_workspace_bytes(), 'optim')
-        if pending is not None or slab is not None:
-            rc = L.acktr_clip_adam_dev_head_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
+        if pending is not None or slab is not None or (image_map is not None and max_grad_norm):
+            rc = L.acktr_clip_adam_dev_pack_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
                                                 _hip.dev_ptr(self.exp_avg_sq), flat.numel(), float(max_grad_norm),
                                                 _hip.dev_ptr(self.hyper_dev), _hip.dev_ptr(self.step_dev, torch.int32),
                                                 ctypes.byref(pending) if pending is not None else None,
                                                 ctypes.byref(slab) if slab is not None else None,
+                                                ctypes.byref(image_map) if image_map is not None else None,
                                                 _hip.dev_ptr(ws), _hip.cur_stream(flat.device))
-            _hip.check(rc, 'acktr_clip_adam_dev_head_f32')
+            _hip.check(rc, 'acktr_clip_adam_dev_pack_f32')
             return
         rc = L.acktr_clip_adam_dev_f32(_hip.dev_ptr(flat), _hip.dev_ptr(gflat), _hip.dev_ptr(self.exp_avg),
                                        _hip.dev_ptr(self.exp_avg_sq), flat.numel(),
@@ -115,6 +117,7 @@ class PPO():
         self._graphs = None
         self._seen_key = None
         self._full_checked = False
+        self._image_map = None
 
     # one minibatch step = ppo.py:57-84
     def _fwd_bwd(self, b, phase=None, with_optimizer=False):
@@ -137,7 +140,7 @@ class PPO():
             return with_optimizer
         fuse_head = b.get('hxs') is None and engine.head_step_ok(ac, nrows)
         acts = engine.forward(ac, b['obs'], gather_idx=b['idx'], rnn_hxs=b.get('hxs'), masks=b.get('masks'),
-                              head=not fuse_head)
+                              head=not fuse_head, trust_images=self._image_map is not None)
         # single process, clipped: the head's slab sums ride in the optimiser's norm launch (one launch fewer per step)
         defer = bool(fuse_head and with_optimizer and self.max_grad_norm and DEFER_HEAD_FINALIZE)
         ret = (engine.head_step if fuse_head else engine.policy_loss)(
@@ -158,7 +161,8 @@ class PPO():
         if self._fwd_bwd(b, with_optimizer=True):
             self.optimizer.step_count += 1
         else:
-            self.optimizer.step(self.max_grad_norm, capturing=capturing, pending=self._pending, slab=self._pending_slab)
+            self.optimizer.step(self.max_grad_norm, capturing=capturing, pending=self._pending, slab=self._pending_slab,
+                                image_map=self._image_map)
             self._pending = self._pending_slab = None
 
     def _dp_step(self, b, split, graphs, capturing=False):
@@ -179,7 +183,7 @@ class PPO():
             graphs[2].replay()
             self.optimizer.step_count += 1
         else:
-            self.optimizer.step(self.max_grad_norm, capturing=capturing)               # ppo.py:82-84
+            self.optimizer.step(self.max_grad_norm, capturing=capturing, image_map=self._image_map)   # ppo.py:82-84
 
     def update(self, rollouts):
         ac = self.actor_critic
@@ -193,7 +197,11 @@ class PPO():
         # num_mini_batch when rows is not a multiple of it (80 rows / 32 -> 40 batches of 2)
         nb = rows // max(mbs, 1)
         lo, hi = self.dp.bounds(mbs)
-        key = (rollouts.obs.data_ptr(), rollouts.actions.data_ptr(), rollouts.returns.data_ptr(),
+        # the conv weight images are re-ordered ONCE per update (whatever happened to the parameters since the last one);
+        # inside the update the Adam steps keep them current, so the minibatch steps have no pack launch
+        with torch.no_grad():
+            self._image_map = engine.refresh_conv_images(ac, hi - lo) if self.max_grad_norm else None
+        key = (self._image_map.base if self._image_map is not None else None, rollouts.obs.data_ptr(), rollouts.actions.data_ptr(), rollouts.returns.data_ptr(),
                rollouts.value_preds.data_ptr(), rollouts.action_log_probs.data_ptr(), T, N, mbs, lo, hi,
                ac.flat_params.data_ptr(), self.clip_param, self.value_loss_coef, self.entropy_coef,
                self.max_grad_norm, self.use_clipped_value_loss)
@@ -249,7 +257,7 @@ class PPO():
                         with torch.cuda.graph(g2):
                             self._fwd_bwd(b, phase=2)
                     with torch.cuda.graph(g3):
-                        self.optimizer.step(self.max_grad_norm, capturing=True)
+                        self.optimizer.step(self.max_grad_norm, capturing=True, image_map=self._image_map)
                         self.optimizer.step_count -= 1
                     self._graphs = (g1, g2, g3)
                 self._graph_key = key
@@ -284,6 +292,7 @@ class PPO():
         N // num_mini_batch envs.  Rows are addressed through one index tensor (t*N + env), so the fused gathers of
         the feed-forward path serve here too; data-parallel ranks split the ENVS of a minibatch."""
         ac = self.actor_critic
+        self._image_map = None                      # (the recurrent step re-orders its conv weights every step)
         T, N = rollouts.rewards.size()[0:2]
         rows = T * N
         dev = rollouts.rewards.device

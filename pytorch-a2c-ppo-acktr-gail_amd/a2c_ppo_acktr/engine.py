@@ -225,8 +225,29 @@ def gru_backward(policy, a, dout, gflat, wgrad=True, dx_gate_src=None, dx_gate=N
     return None
 
 
-def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True):
-    """head=False stops at the FC features (`head_step` then runs head, loss and their backward in one launch)."""
+def _conv_image_layers(L):
+    return [('f1', L['conv1'][0], 4, 84, False), ('f2', L['conv2'][0], 2, 20, False), ('f3', L['conv3'][0], 1, 9, False),
+            ('d3', L['conv3'][0], 1, 9, True), ('d2', L['conv2'][0], 2, 20, True)]
+
+
+def refresh_conv_images(policy, B):
+    """Re-order the conv weights into the stationary kernels' images NOW (one launch) and return the _hip.PackMap with
+    which an optimiser keeps them current (acktr_clip_adam_dev_pack_f32), or None when the policy has no such images.
+    An update loop calls this once per update() and then runs forward(..., trust_images=True): between two updates
+    anybody may have changed the parameters, inside one only the optimiser does."""
+    if not is_cnn(policy) or not TRUST_IMAGES:
+        return None
+    L = cnn_layer_params(policy)
+    layers = _conv_image_layers(L)
+    cache = policy.__dict__.setdefault('_pack_ws', {})
+    if not ops.pack_conv_weights(layers, B, cache):
+        return None
+    return ops.conv_image_map(layers, B, cache, lambda w: policy._offsets[id(w)][0])
+
+
+def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True, trust_images=False):
+    """head=False stops at the FC features (`head_step` then runs head, loss and their backward in one launch).
+    trust_images: see refresh_conv_images."""
     inputs = inputs.contiguous()
     _check_input(policy, inputs, gather_idx)
     rec = policy.is_recurrent
@@ -237,10 +258,8 @@ def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True
         B = inputs.shape[0] if gather_idx is None else gather_idx.numel()
         # all five re-ordered weight images of the step (three forward, two dgrad) in one launch; the parameters do
         # not change between this forward and its backward
-        pk = ops.pack_conv_weights([('f1', L['conv1'][0], 4, 84, False), ('f2', L['conv2'][0], 2, 20, False),
-                                    ('f3', L['conv3'][0], 1, 9, False), ('d3', L['conv3'][0], 1, 9, True),
-                                    ('d2', L['conv2'][0], 2, 20, True)], B,
-                                   policy.__dict__.setdefault('_pack_ws', {}))
+        pk = ops.pack_conv_weights(_conv_image_layers(L), B, policy.__dict__.setdefault('_pack_ws', {}),
+                                   trust=trust_images and TRUST_IMAGES)
         a.packs = pk
         a.y1 = ops.conv2d_fwd(inputs, L['conv1'][0], L['conv1'][1].view(-1), 4, in_scale=1.0 / 255.0, relu=True,
                               gather_idx=gather_idx, packed=pk.get('f1'))
@@ -447,6 +466,7 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
 FUSED_HEAD = os.environ.get('ACKTR_FUSED_HEAD', '1') != '0'
 FOLD_FC_SLABS = os.environ.get('ACKTR_FOLD_FC_SLABS', '1') != '0'      # comparison switch
 CARRY_SLABS = os.environ.get('ACKTR_CARRY_SLABS', '1') != '0'          # comparison switch
+TRUST_IMAGES = os.environ.get('ACKTR_ADAM_PACKS', '1') != '0'          # comparison switch (optimiser keeps the weight images)
 
 
 def head_step_ok(policy, B):

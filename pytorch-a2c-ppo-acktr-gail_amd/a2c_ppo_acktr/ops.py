@@ -82,14 +82,11 @@ def _conv_out(H, K, S):
     return (H - K) // S + 1
 
 
-def pack_conv_weights(layers, B, cache):
-    """Re-ordered weights of several conv layers in ONE launch.  layers: list of (key, w, stride, in_hw, dgrad); the
-    result maps key -> workspace tensor to hand to conv2d_fwd / conv2d_dgrad as `packed`.  Layers the stationary
-    kernels do not cover are left out (those entry points then prepare their weights themselves).  `cache` (a dict
-    owned by the policy) keeps the workspaces: they must survive from a forward to its backward, so they cannot be
-    the process-wide scratch buffers."""
+def _pack_layout(layers, B):
+    """[(key, byte offset, bytes, job tuple)] of the weight-image workspaces inside ONE buffer (256-byte aligned slots),
+    and the buffer size.  Layers the stationary kernels do not cover are left out."""
     L = _hip.lib()
-    jobs, out = [], {}
+    out, off = [], 0
     for key, w, stride, hw, dgrad in layers:
         OC, C, KH, KW = w.shape
         if dgrad:
@@ -98,20 +95,105 @@ def pack_conv_weights(layers, B, cache):
             nb = L.acktr_conv2d_fwd_workspace_bytes(C, hw, hw, OC, KH, KW, stride)
         if not nb or (w.data_ptr() & 15):
             continue
-        ws = cache.get(key)
-        if ws is None or ws.numel() < nb or ws.device != w.device:
-            # zeroed: behind the weight image a dgrad workspace holds the zero-padded dY planes, whose borders nobody
-            # writes when the producer of dY fills the interiors itself (padded_dy_view / conv2d_dgrad(dy_prepadded))
-            ws = cache[key] = torch.zeros(int(nb), dtype=torch.uint8, device=w.device)
-        jobs.append(_hip.ConvPackJob(w.data_ptr(), ws.data_ptr(), ws.numel(), C, hw, hw, OC, KH, KW, stride,
-                                     1 if dgrad else 0))
-        out[key] = ws
-    if jobs:
-        arr = (_hip.ConvPackJob * len(jobs))(*jobs)
-        rc = L.acktr_conv2d_pack_weights_f32(arr, len(jobs), _hip.cur_stream(layers[0][1].device))
-        if rc != 0:            # a layer outside the stationary kernels' shapes: fall back to per-call preparation
+        out.append((key, off, int(nb), (C, hw, OC, KH, KW, stride, 1 if dgrad else 0)))
+        off += (int(nb) + 255) // 256 * 256
+    return out, off
+
+
+def _pack_jobs(layout, weights, buf):
+    jobs = [_hip.ConvPackJob(weights[key].data_ptr(), buf.data_ptr() + off, nb, C, hw, hw, OC, KH, KW, stride, dg)
+            for key, off, nb, (C, hw, OC, KH, KW, stride, dg) in layout]
+    return (_hip.ConvPackJob * len(jobs))(*jobs)
+
+
+def _run_pack(layout, weights, buf, stream_dev):
+    arr = _pack_jobs(layout, weights, buf)
+    return _hip.lib().acktr_conv2d_pack_weights_f32(arr, len(arr), _hip.cur_stream(stream_dev))
+
+
+def pack_conv_weights(layers, B, cache, trust=False):
+    """Re-ordered weights of several conv layers in ONE launch.  layers: list of (key, w, stride, in_hw, dgrad); the
+    result maps key -> workspace tensor to hand to conv2d_fwd / conv2d_dgrad as `packed`.  Layers the stationary
+    kernels do not cover are left out (those entry points then prepare their weights themselves).  `cache` (a dict
+    owned by the policy) keeps the workspaces: they must survive from a forward to its backward, so they cannot be
+    the process-wide scratch buffers.  All workspaces are slots of ONE buffer, so that an optimiser can keep the images
+    in step with the parameters through one offset table (conv_image_map).
+    trust=True: the images are known to be current (the caller re-packed at the start of its update and its optimiser
+    steps write the images themselves): no launch."""
+    if not layers:
+        return {}
+    dev = layers[0][1].device
+    wptr = layers[0][1].data_ptr()
+    if cache.get('_jobs') is not None and cache.get('_B', 0) >= B and cache.get('_wptr') == wptr and cache['_buf'].device == dev:
+        # the common case, without the host work of laying the buffer out again (it showed as GPU idle time in front of
+        # every update's first graph launch): same parameters, a batch the buffer already covers
+        if not trust:
+            if _hip.lib().acktr_conv2d_pack_weights_f32(cache['_jobs'], len(cache['_jobs']), _hip.cur_stream(dev)) != 0:
+                return {}
+        return cache['_views']
+    # sized for the largest batch seen so far: a smaller batch (Policy.act between two updates) uses the front of the same
+    # slots, so captured graphs that hold pointers into the buffer stay valid; an outgrown buffer is retired, not freed
+    B = max(int(B), cache.get('_B', 0) if cache.get('_buf') is not None and cache['_buf'].device == dev else 0)
+    layout, total = _pack_layout(layers, B)
+    if not layout:
+        return {}
+    sig = tuple((k, o, n) for k, o, n, _ in layout)
+    buf = cache.get('_buf')
+    fresh = buf is None or buf.device != dev or cache.get('_sig') != sig
+    if fresh:
+        if buf is not None:
+            _ws_retired.append(buf)
+        cache['_B'] = B
+        # zeroed: behind the weight image a dgrad workspace holds the zero-padded dY planes, whose borders nobody
+        # writes when the producer of dY fills the interiors itself (padded_dy_view / conv2d_dgrad(dy_prepadded))
+        buf = torch.zeros(total, dtype=torch.uint8, device=dev)
+        cache['_buf'], cache['_sig'], cache['_map'] = buf, sig, None
+        cache['_views'] = {k: buf[o:o + n] for k, o, n, _ in layout}
+    weights = {key: w for key, w, _, _, _ in layers}
+    if fresh or not trust:
+        if _run_pack(layout, weights, buf, dev) != 0:      # a layer outside the stationary kernels' shapes
             return {}
-    return out
+    cache['_jobs'] = _pack_jobs(layout, weights, buf)
+    cache['_wptr'] = wptr
+    return cache['_views']
+
+
+def conv_image_map(layers, B, cache, offset_of):
+    """_hip.PackMap for an optimiser that stores conv weights to their weight-image slots as it updates them
+    (acktr_clip_adam_dev_pack_f32), or None.  offset_of(w) -> float offset of parameter w in the flat buffer.  The
+    tables come from the pack kernel itself: it is run once on weights that hold their own element number, and every
+    image slot then says which parameter element it wants."""
+    if cache.get('_map') is not None and cache.get('_jobs') is not None and cache.get('_B', 0) >= B:
+        return cache['_map'][0]
+    if not pack_conv_weights(layers, B, cache, trust=True):
+        return None
+    if cache.get('_map') is not None:
+        return cache['_map'][0]
+    dev = cache['_buf'].device
+    layout, total = _pack_layout(layers, cache['_B'])
+    by_key = {key: w for key, w, _, _, _ in layers}
+    lo = min(offset_of(w) for w in by_key.values())
+    hi = max(offset_of(w) + w.numel() for w in by_key.values())
+    idx_w = {key: (torch.arange(1, w.numel() + 1, dtype=torch.float32, device=dev).view(w.shape).contiguous())
+             for key, w in by_key.items()}
+    if max(w.numel() for w in by_key.values()) >= (1 << 24):
+        return None
+    tmp = torch.zeros(total, dtype=torch.uint8, device=dev)
+    if _run_pack(layout, idx_w, tmp, dev) != 0:
+        return None
+    img = tmp.view(torch.float32)
+    t = [torch.full((hi - lo,), -1, dtype=torch.int32, device=dev) for _ in range(2)]
+    for key, off, nb, job in layout:
+        region = img[off // 4:(off + nb) // 4]
+        slots = region.nonzero().view(-1)
+        elems = region[slots].long() - 1 + (offset_of(by_key[key]) - lo)
+        which = t[1] if job[-1] else t[0]
+        if bool((which[elems] >= 0).any()):
+            return None                        # two images of one kind want the same parameter: not a layout this map covers
+        which[elems] = (slots + off // 4).to(torch.int32)
+    pm = _hip.PackMap(lo, hi, t[0].data_ptr(), t[1].data_ptr(), cache['_buf'].data_ptr())
+    cache['_map'] = (pm, t)                    # (the tables stay alive with the cache)
+    return pm
 
 
 def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out=None, packed=None):

@@ -96,7 +96,7 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
                                                                   float max_norm, float lr_or_step, float beta1,
                                                                   float beta2, float eps, float bc2_sqrt,
                                                                   float* norm_out, const float* hyper_dev,
-                                                                  const int* step_dev) {
+                                                                  const int* step_dev, const acktr_pack_map map) {
     __shared__ float sm2[2];
     __shared__ float sm_adam[2];
     float coef = 1.0f;
@@ -157,6 +157,19 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
         if (use_clip) reinterpret_cast<v4*>(g)[i] = gv;
         reinterpret_cast<v4*>(s1)[i] = av;
         if (MODE == 0) reinterpret_cast<v4*>(s2)[i] = bv;
+        // the new values of the conv weights also go to their slots in the stationary kernels' weight images (forward
+        // and input-gradient layouts), so the next step starts without a re-ordering launch
+        if (map.t1 && 4 * i + 3 >= map.lo && 4 * i < map.hi) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const long e = 4 * i + j - map.lo;
+                if (e >= 0 && 4 * i + j < map.hi) {
+                    const int d1 = map.t1[e], d2 = map.t2[e];
+                    if (d1 >= 0) map.base[d1] = pv[j];
+                    if (d2 >= 0) map.base[d2] = pv[j];
+                }
+            }
+        }
     }
     for (long i = 4 * n4 + (long)blockIdx.x * OPT_THREADS + threadIdx.x; i < n; i += (long)gridDim.x * OPT_THREADS) {
         float pi = p[i], gi = g[i], a1 = s1[i], a2 = MODE == 0 ? s2[i] : 0.f;
@@ -165,6 +178,11 @@ __global__ __launch_bounds__(OPT_THREADS) void clip_update_kernel(float* p, floa
         if (use_clip) g[i] = gi;
         s1[i] = a1;
         if (MODE == 0) s2[i] = a2;
+        if (map.t1 && i >= map.lo && i < map.hi) {
+            const int d1 = map.t1[i - map.lo], d2 = map.t2[i - map.lo];
+            if (d1 >= 0) map.base[d1] = pi;
+            if (d2 >= 0) map.base[d2] = pi;
+        }
     }
 }
 
@@ -212,7 +230,7 @@ extern "C" int acktr_clip_adam_f32(float* params, float* grads, float* exp_avg, 
     }
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
                        (const double*)workspace, nb, use_clip, max_grad_norm, step_size, beta1, beta2, eps,
-                       bias_correction2_sqrt, total_norm_out, (const float*)nullptr, (const int*)nullptr);
+                       bias_correction2_sqrt, total_norm_out, (const float*)nullptr, (const int*)nullptr, acktr_pack_map{});
     ACKTR_LAUNCH_CHECK();
     return 0;
 }
@@ -234,7 +252,7 @@ extern "C" int acktr_clip_adam_dev_f32(float* params, float* grads, float* exp_a
     }
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
                        (const double*)workspace, nb, use_clip, max_grad_norm, 0.f, 0.f, 0.f, 0.f, 1.f, (float*)nullptr,
-                       hyper_dev, (const int*)step_dev);
+                       hyper_dev, (const int*)step_dev, acktr_pack_map{});
     ACKTR_LAUNCH_CHECK();
     return 0;
 }
@@ -243,7 +261,20 @@ extern "C" int acktr_clip_adam_dev_head_f32(float* params, float* grads, float* 
                                             float max_grad_norm, const float* hyper_dev, int* step_dev,
                                             const acktr_head_fin* pending, const acktr_slab_fin* slab, void* workspace,
                                             void* stream) {
+    return acktr_clip_adam_dev_pack_f32(params, grads, exp_avg, exp_avg_sq, n, max_grad_norm, hyper_dev, step_dev, pending,
+                                        slab, nullptr, workspace, stream);
+}
+
+extern "C" int acktr_clip_adam_dev_pack_f32(float* params, float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                                            float max_grad_norm, const float* hyper_dev, int* step_dev,
+                                            const acktr_head_fin* pending, const acktr_slab_fin* slab,
+                                            const acktr_pack_map* map, void* workspace, void* stream) {
     ACKTR_ARG(params && grads && exp_avg && exp_avg_sq && workspace && hyper_dev && step_dev, "clip_adam_dev_head: null pointer");
+    acktr_pack_map pm = {};
+    if (map && map->t1) {
+        pm = *map;
+        ACKTR_ARG(pm.t2 && pm.base && pm.lo >= 0 && pm.lo < pm.hi && pm.hi <= n, "clip_adam_dev_pack: bad weight-image map");
+    }
     ACKTR_ARG(n > 0 && max_grad_norm > 0.f, "clip_adam_dev_head: needs n > 0 and a clip norm (the pending sums ride in the norm launch)");
     acktr_head_fin f = {};
     acktr_slab_fin r = {};
@@ -275,7 +306,7 @@ extern "C" int acktr_clip_adam_dev_head_f32(float* params, float* grads, float* 
     ACKTR_LAUNCH_CHECK();
     hipLaunchKernelGGL((clip_update_kernel<0>), dim3(grid_for(n)), dim3(OPT_THREADS), 0, s, params, grads, exp_avg, exp_avg_sq, n,
                        (const double*)workspace, total, 1, max_grad_norm, 0.f, 0.f, 0.f, 0.f, 1.f, (float*)nullptr,
-                       hyper_dev, (const int*)step_dev);
+                       hyper_dev, (const int*)step_dev, pm);
     ACKTR_LAUNCH_CHECK();
     return 0;
 }
@@ -294,7 +325,7 @@ extern "C" int acktr_clip_rmsprop_f32(float* params, float* grads, float* square
     }
     hipLaunchKernelGGL((clip_update_kernel<1>), dim3(nb), dim3(OPT_THREADS), 0, s, params, grads, square_avg,
                        (float*)nullptr, n, (const double*)workspace, nb, use_clip, max_grad_norm, lr, 0.f, alpha, eps, 1.f,
-                       total_norm_out, (const float*)nullptr, (const int*)nullptr);
+                       total_norm_out, (const float*)nullptr, (const int*)nullptr, acktr_pack_map{});
     ACKTR_LAUNCH_CHECK();
     return 0;
 }

@@ -178,6 +178,43 @@ def test_ppo_deferred_head_finalize_matches_own_launch():
     np.testing.assert_allclose(out[True][1], out[False][1], rtol=0, atol=2e-7)
 
 
+def test_ppo_optimizer_kept_weight_images_match_repacking():
+    """Inside one PPO.update the Adam steps store the new conv weights straight into the stationary kernels' weight
+    images (acktr_clip_adam_dev_pack_f32) and the minibatch steps run without a pack launch (engine.TRUST_IMAGES);
+    update() itself re-packs once at its start.  Against re-packing in every step: bit-identical losses and parameters
+    over four updates (two of them graph replays), with the parameters edited behind the optimiser's back between
+    updates (p.data edits, which no version counter sees) and a rollout-side act() at another batch size in between."""
+    from a2c_ppo_acktr import algo, engine
+    ci = [i for i, c in enumerate(PPO_CASES) if c[1] == 'cnn'][0]
+    tag, kind, od, A, T, N, hp = PPO_CASES[ci]
+    ro = synth.make_rollouts(T, N, (4, 84, 84), 'discrete', A, salt=735)
+    out = {}
+    saved = engine.TRUST_IMAGES
+    try:
+        for trust in (True, False):
+            engine.TRUST_IMAGES = trust
+            pol = make_policy(kind, od, A, 62)
+            rs = make_storage(ro, (4, 84, 84), Discrete(A))
+            rs.compute_returns(t(ro['next_value']).cuda(), True, 0.99, 0.95, True)
+            agent = algo.PPO(pol, **hp)
+            losses, acted = [], []
+            for it in range(4):
+                torch.manual_seed(300 + it)
+                losses.append(agent.update(rs))
+                assert (agent._image_map is not None) == trust
+                with torch.no_grad():
+                    for p in pol.parameters():
+                        p.data.mul_(0.97)                               # an edit the optimiser never hears of
+                    v, a, lp, _ = pol.act(rs.obs[it][:5], None, None, deterministic=True)     # other batch size, same images
+                acted.append(v.cpu().numpy().copy())
+            out[trust] = (np.array(losses), pol.flat_params.detach().cpu().numpy().copy(), np.array(acted))
+    finally:
+        engine.TRUST_IMAGES = saved
+    assert np.array_equal(out[True][0], out[False][0])
+    assert np.array_equal(out[True][1], out[False][1])
+    assert np.array_equal(out[True][2], out[False][2])
+
+
 @pytest.mark.parametrize('kind', ['mlp', 'cnn'])
 def test_ppo_rows_not_multiple_of_minibatches(kind):
     """The reference's defaults (arguments.py: 5 steps x 16 processes, num_mini_batch 32): 80 rows give batches of 2 and

@@ -113,6 +113,36 @@ def cpu_baseline(ro_cpu, seed, max_updates=12, budget_s=12.0):
                        % (n_upd, T, N, T * N // PPO_HP['num_mini_batch'], dt)), losses
 
 
+def _profile_traffic(op, stats_kind, traffic_kind):
+    """HBM-side bytes per launch of operator `op` from the newest committed counter summary
+    profiles/rN_<traffic_kind>_<tag>.json (separate rocprofv3 --pmc passes of this command, tools/profile_round.sh +
+    tools/pmc_traffic.py) -- refused (None, with the reason) when a NEWER kernel-stats summary rN_<stats_kind>_<tag>.csv
+    exists, i.e. when the kernels were profiled again after the counters were taken.  Returns (bytes or None, source)."""
+    import glob
+    import re
+
+    def newest(pattern, rx):
+        best = None
+        for f in glob.glob(os.path.join(ROOT, 'profiles', pattern)):
+            m = re.match(rx, os.path.basename(f))
+            if m and (best is None or (int(m.group(1)), m.group(2)) > best[0]):
+                best = ((int(m.group(1)), m.group(2)), f)
+        return best
+    try:
+        tr = newest('r*_%s_*.json' % traffic_kind, r'r(\d+)_%s_(\w+)\.json$' % traffic_kind)
+        ks = newest('r*_%s_*.csv' % stats_kind, r'r(\d+)_%s_(\w+)\.csv$' % stats_kind)
+        if tr is None:
+            return None, 'no profiles/r*_%s_*.json' % traffic_kind
+        tags = 'counters r%d tag %s, kernel stats %s' % (tr[0][0], tr[0][1], 'r%d tag %s' % ks[0] if ks else 'none')
+        if ks is not None and ks[0] > tr[0]:
+            return None, 'refused: %s are newer than the counter passes (%s)' % (os.path.basename(ks[1]), tags)
+        val = json.load(open(tr[1])).get(op, {}).get('traffic_bytes')
+        return val, 'profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes; %s)' % (
+            os.path.basename(tr[1]), tags)
+    except Exception as e:
+        return None, 'unreadable: %r' % (e,)
+
+
 def _timed_updates(agent, rs, n, seed0):
     """ms of each of n consecutive update() calls (device-synchronised around every call)."""
     out = []
@@ -194,8 +224,10 @@ def side_metrics(device):
         fac = {k: v for k, v in kprof.items() if k.startswith('kfac_cov_a_conv')}
         dom = max(fac.items(), key=lambda kv: kv[1]['total_ms'])
         ach = dom[1]['flops_per_call'] / (dom[1]['avg_ms'] * 1e-3) / 1e12
+        ktraffic, ktraffic_src = _profile_traffic(dom[0], 'acktr_kernel_stats', 'acktr_pmc_traffic')
         out['roofline_kfac'] = dict(bound='mfma', kernel=dom[0], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,
-                                    unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=None,
+                                    unit='TFLOP/s', frac=round(ach / MFMA_F32_PEAK_TFLOPS, 4), traffic=ktraffic,
+                                    traffic_source=ktraffic_src,
                                     avg_launch_ms=round(dom[1]['avg_ms'], 4), flop_per_launch=dom[1]['flops_per_call'],
                                     flop_count='symmetric half R*D*(D+1) (SURVEY 8(d)); the kernels compute the upper '
                                                'triangle of 32x32 tiles (stationary accumulators) and mirror it',
@@ -578,17 +610,7 @@ def main():
         gemm_ms = sum(v['total_ms'] for v in prof.values())
         gemm_flop = sum(v['flops_per_call'] * v['calls'] for v in prof.values())
         roof = None
-        traffic, traffic_src = None, None
-        try:      # HBM-side bytes per launch from separate rocprofv3 --pmc passes of this command (tools/pmc_traffic.py)
-            import glob
-            import re
-            cands = glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic_*.json'))
-            key = lambda f: (tuple(int(x) for x in re.findall(r'\d+', os.path.basename(f))), os.path.basename(f))   # round, tag
-            tp = max(cands, key=key)
-            traffic = json.load(open(tp))[dom[0]]['traffic_bytes']
-            traffic_src = 'profiles/%s (2*FETCH_SIZE + WRITE_SIZE per launch, separate --pmc passes)' % os.path.basename(tp)
-        except Exception:
-            pass
+        traffic, traffic_src = _profile_traffic(dom[0], 'headline_kernel_stats', 'pmc_traffic')
         if dom[0] is not None:
             ach = dom[1]['flops_per_call'] / (dom[1]['avg_ms'] * 1e-3) / 1e12
             roof = dict(bound='mfma', kernel=dom[0], achieved=round(ach, 2), peak=MFMA_F32_PEAK_TFLOPS,

@@ -5,7 +5,8 @@ rows.sort(key=lambda r: int(r['Start_Timestamp']))
 def short(n):
     n = re.sub(r'acktr::', '', n); n = re.sub(r'void ', '', n)
     return n[:64]
-idx = [i for i, r in enumerate(rows) if 'policy_loss_kernel' in r['Kernel_Name']]
+idx = [i for i, r in enumerate(rows) if 'head_step_kernel' in r['Kernel_Name']] or \
+    [i for i, r in enumerate(rows) if 'policy_loss_kernel' in r['Kernel_Name']]
 i0 = idx[len(idx) // 2]
 # step = from the previous clip_update end to this step's clip_update end
 j = i0

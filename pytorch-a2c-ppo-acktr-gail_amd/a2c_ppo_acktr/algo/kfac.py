@@ -226,7 +226,20 @@ class KFACOptimizer(optim.Optimizer):
         self._ready_device = dev
 
     # ------------------------------------------------------------------ statistics (kfac.py:144-177)
-    def _cov_dense(self, a2d, ptr, ld, B, D, alpha, out):
+    def _cov_dense(self, a2d, ptr, ld, B, D, alpha, out, share=False):
+        # Two modules that see the same tensor get the same factor: critic_linear and dist.linear both read the FC features
+        # (A), a Linear and the AddBias behind it receive the same grad_output (G; kfac.py:59-64 is a no-op on 2-D
+        # gradients).  The reference computes each twice; here the second one is a copy of the first (same bits).
+        # (share: only for operands that live on `acts` for the whole statistics pass -- a temporary's address can be
+        #  reused by the next temporary)
+        seen = self.__dict__.get('_cov_seen') if share else None
+        key = (ptr, ld, B, D, float(alpha))
+        if seen is not None:
+            prev = seen.get(key)
+            if prev is not None and D > 1:
+                out.copy_(prev)
+                return
+            seen[key] = out
         L = _hip.lib()
         ws = ops.workspace(out.device, L.acktr_kfac_cov_workspace_bytes(D, B), 'kfac')
         with ops._Timed('kfac_cov_dense%d' % D, float(B) * D * (D + 1)):
@@ -310,6 +323,7 @@ class KFACOptimizer(optim.Optimizer):
         L = _hip.lib()
         stream = _hip.cur_stream(dev)
         view_a = lambda m: self.aa_sample[m.oa:m.oa + m.na * m.na]
+        self._cov_seen = {}
 
         # ---- A factors: compute_cov_a on the layer inputs (kfac.py:29-46)
         if cnn:
@@ -364,7 +378,7 @@ class KFACOptimizer(optim.Optimizer):
                 _hip.check(rc, 'acktr_kfac_cov_a_conv_f32')
             else:
                 a = lin_in[m.layer]
-                self._cov_dense(a, a.data_ptr(), a.shape[1], B, a.shape[1], 1.0 / Bg, out)
+                self._cov_dense(a, a.data_ptr(), a.shape[1], B, a.shape[1], 1.0 / Bg, out, share=True)
 
 
     def _stats_g(self, acts, B, Bg, dls_rows):
@@ -376,6 +390,7 @@ class KFACOptimizer(optim.Optimizer):
         stream = _hip.cur_stream(dev)
         gauss = pol.dist.kind == 1
         view_g = lambda m: self.gg_sample[m.og:m.og + m.ng * m.ng]
+        self._cov_seen = {}
         # ---- G factors: compute_cov_g on the grad_outputs (kfac.py:49-64)
         if cnn:
             conv_g = {'conv1': acts.dy1, 'conv2': acts.dy2, 'conv3': acts.dy3}
@@ -412,7 +427,7 @@ class KFACOptimizer(optim.Optimizer):
                     self._cov_dense(ssum, ssum.data_ptr(), OC, B, OC, float(Bg), out)
             else:
                 ptr, ld, D = lin_g[m.layer]
-                self._cov_dense(None, ptr, ld, B, D, float(Bg), out)
+                self._cov_dense(None, ptr, ld, B, D, float(Bg), out, share=True)
 
     # ------------------------------------------------------------------ eigendecompositions (kfac.py:205-214)
     def _eigendecompose(self):

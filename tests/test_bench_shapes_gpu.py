@@ -146,3 +146,44 @@ def test_minibatch_8192_from_full_size_storage():
     for a, b in zip(losses_big, (vl.item(), al.item(), en.item())):
         assert abs(a - b) <= TOL * max(abs(b), 1e-3), ('losses', losses_big, (vl.item(), al.item(), en.item()))
     assert bool(torch.isfinite(g_big).all()) and float(g_big.abs().max()) > 0
+
+
+def test_ppo_update_is_run_to_run_deterministic():
+    """Two fresh agents, same seeds, three updates each at the benchmarked minibatch size (1024 rows through the index; the
+    third update replays the captured epoch graph): every reduction on the path -- split-K slabs, the slab sums that ride in
+    the next launch as extra workgroups, the head step's finalize, the gradient norm -- runs in a fixed order, so losses and
+    parameters must agree bit for bit."""
+    from a2c_ppo_acktr import algo
+    from a2c_ppo_acktr.model import Policy
+    from a2c_ppo_acktr.storage import RolloutStorage
+
+    class Discrete(object):
+        n = 6
+    T, N = 128, 32
+    g = torch.Generator().manual_seed(77)
+    obs = torch.randint(0, 256, (T + 1, N, 4, 84, 84), generator=g, dtype=torch.int32).to(torch.uint8)
+    small = {k: torch.randn(*shape, generator=g) for k, shape in (('rewards', (T, N, 1)), ('value_preds', (T + 1, N, 1)))}
+    alp = 0.1 * torch.randn(T, N, 1, generator=g) - 1.8
+    act = torch.randint(0, 6, (T, N, 1), generator=g)
+    masks = (torch.rand(T + 1, N, 1, generator=g) < 0.99).float()
+    res = []
+    for rep in range(2):
+        torch.manual_seed(5)
+        pol = Policy((4, 84, 84), Discrete())
+        pol.to('cuda')
+        rs = RolloutStorage(T, N, (4, 84, 84), Discrete(), 1)
+        rs.to('cuda')
+        rs.obs.copy_(obs.cuda())
+        rs.rewards.copy_(small['rewards']); rs.value_preds.copy_(small['value_preds'])
+        rs.action_log_probs.copy_(alp); rs.actions.copy_(act); rs.masks.copy_(masks)
+        rs.compute_returns(torch.zeros(N, 1).cuda(), True, 0.99, 0.95, True)
+        agent = algo.PPO(pol, 0.1, 2, 4, 0.5, 0.01, lr=2.5e-4, eps=1e-5, max_grad_norm=0.5)
+        losses = []
+        for it in range(3):
+            torch.manual_seed(40 + it)
+            losses.append(agent.update(rs))
+        res.append((np.array(losses), pol.flat_params.detach().clone()))
+        del rs, agent, pol
+        torch.cuda.empty_cache()
+    assert np.array_equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1].view(torch.int32), res[1][1].view(torch.int32))

@@ -119,7 +119,11 @@ int acktr_conv2d_dgrad_f32(const float* dy, const float* w, const float* x_act, 
  *   padded by 2, 9x9 dY padded by 1), written there by the producer of dY; `dy` may then be NULL and the padding launch
  *   is skipped.  The caller keeps the borders of that region zero (allocate it zeroed; producers write interiors only).
  *   dx_padded (nullable; 3x3 stride-1 stationary path only): dx is ALSO written as [B, C, H+2*pad, W+2*pad] planes,
- *   interior only -- point it at the next layer's padded-dY region. */
+ *   interior only -- point it at the next layer's padded-dY region.
+ * ..._padded_dy_offset_bytes returns -1 for a shape whose kernel reads dY as it is -- NatureCNN's third layer (64 <- 32
+ * channels, 3x3 stride 1, model.py:179) runs in overlap-add form over the 49 real positions of an image
+ * (csrc/conv3_dgrad_oa.hpp; ACKTR_D3_OA=0 in the environment selects the gather over the padded dY instead): pass `dy`
+ * and leave flags bit 1 clear then; dx_padded is served all the same. */
 long acktr_conv2d_dgrad_padded_dy_offset_bytes(int C, int H, int W, int OC, int KH, int KW, int S);
 int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H, int W,
                               int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, int flags,

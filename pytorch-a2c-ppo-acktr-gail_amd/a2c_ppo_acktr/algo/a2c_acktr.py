@@ -77,7 +77,7 @@ class A2C_ACKTR():
             pg.items.append(lambda: self.dp.all_reduce_sum_(self._loss_acc))
             return pg
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with ops.graph_capture(g):
             self._loss_acc.zero_()                  # (a node of the graph: no launch of its own per update)
             self._update(rollouts, self._loss_acc)
         return g

@@ -206,7 +206,7 @@ class Discriminator(nn.Module):
                 return loss
             self.optimizer.prepare()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with ops.graph_capture(g):
                 st['loss'] = call(*st['inp'])
                 self.optimizer.step(max_grad_norm=None, capturing=True)
                 self.optimizer.step_count -= 1

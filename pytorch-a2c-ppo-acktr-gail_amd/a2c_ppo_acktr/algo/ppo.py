@@ -12,7 +12,7 @@ import os
 import torch
 
 from .. import _hip, engine, ops
-from ..parallel import DataParallel, bounded_sync
+from ..parallel import DataParallel, bounded_sync, quiesce_collectives
 
 # ACKTR_DEFER_HEAD=0: the head step finalizes in its own launch (comparison switch)
 DEFER_HEAD_FINALIZE = os.environ.get('ACKTR_DEFER_HEAD', '1') != '0'
@@ -240,7 +240,9 @@ class PPO():
                 if per_pos:
                     self._idx_all = torch.zeros(nb, hi - lo, dtype=torch.int64, device=dev)
                     g = torch.cuda.CUDAGraph()              # the whole epoch: nb steps back to back
-                    with torch.cuda.graph(g):
+                    if full:
+                        quiesce_collectives(dev)
+                    with ops.graph_capture(g):
                         for k in range(nb):
                             if self.dp.active:
                                 self._dp_step(dict(b, idx=self._idx_all[k]), split, None, capturing=True)
@@ -250,13 +252,13 @@ class PPO():
                     self._graphs = (g,)
                 else:                                       # the all-reduce(s) sit between the graphs
                     g1, g2, g3 = torch.cuda.CUDAGraph(), None, torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g1):
+                    with ops.graph_capture(g1):
                         self._fwd_bwd(b, phase=1 if split is not None else None)
                     if split is not None:
                         g2 = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g2):
+                        with ops.graph_capture(g2):
                             self._fwd_bwd(b, phase=2)
-                    with torch.cuda.graph(g3):
+                    with ops.graph_capture(g3):
                         self.optimizer.step(self.max_grad_norm, capturing=True, image_map=self._image_map)
                         self.optimizer.step_count -= 1
                     self._graphs = (g1, g2, g3)
@@ -333,7 +335,7 @@ class PPO():
                           inv_batch=1.0 / (T * ne))
                 if self._rgraph is None:                    # capture (records only; executes nothing)
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
+                    with ops.graph_capture(g):
                         self._fwd_bwd(gb)
                         self.optimizer.step(self.max_grad_norm, capturing=True)
                         self.optimizer.step_count -= 1

@@ -381,7 +381,9 @@ def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None, defer_last
             dfeat, dy3 = acts.dfeat, acts.dy3
             carry3 = None
         pd3 = acts.pd3
-        pd2 = acts.pd2 if pd3 is not None else None           # (conv3 dgrad off the stationary path: nobody fills pd2)
+        # (conv3 dgrad off the stationary path: nobody fills pd2.  pd3 is None with a 'd3' image when that layer's dgrad
+        #  reads dY unpadded: the overlap-add kernel, csrc/conv3_dgrad_oa.hpp)
+        pd2 = acts.pd2 if acts.packs.get('d3') is not None else None
         dy2 = ops.conv2d_dgrad(dy3, w3, acts.y2, 1, packed=acts.packs.get('d3'), dy_prepadded=pd3 is not None,
                                padded_out=pd2, carry=carry3)
         carry2 = _hip.SlabFin() if (wgrad and CARRY_SLABS) else None

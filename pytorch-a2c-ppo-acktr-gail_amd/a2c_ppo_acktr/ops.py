@@ -4,7 +4,9 @@ Thin plumbing only: shape checks on the host (a wrong shape must never reach a
 kernel), device pointers + the current stream handed to the library.  Every
 function requires fp32 contiguous GPU tensors and raises otherwise.
 """
+import contextlib
 import ctypes
+import gc
 import torch
 
 from . import _hip
@@ -71,7 +73,28 @@ def workspace(device, nbytes, tag='ws'):
         want = max(int(nbytes), WS_MIN_BYTES, 2 * buf.numel() if buf is not None else 0)
         buf = torch.empty(want, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
-    return buf
+    # exactly the bytes asked for: several entry points cut their reduction into as many split-K slabs as the workspace
+    # they are GIVEN holds, so handing over the whole (grown) buffer made results depend on what had run before in the
+    # process -- by one rounding, which a ReLU gate at zero can turn into another trajectory (tests/test_u8_gpu.py)
+    return buf[:nbytes] if nbytes < buf.numel() else buf
+
+
+@contextlib.contextmanager
+def graph_capture(g, **kw):
+    """`with torch.cuda.graph(g)` with Python's cyclic garbage collector OFF for the duration.  torch collects once on
+    entry, but a collection that the allocation counters trigger DURING the capture can still finalise an unreachable
+    torch.cuda.CUDAGraph (a dropped agent's, kept alive until then by a reference cycle): its destructor calls into HIP,
+    which answers "operation not permitted when stream is capturing", and torch aborts the process from the destructor
+    (seen once in the GPU suite, inside the GAIL step's capture)."""
+    was_enabled = gc.isenabled()
+    gc.collect()
+    gc.disable()
+    try:
+        with torch.cuda.graph(g, **kw):
+            yield g
+    finally:
+        if was_enabled:
+            gc.enable()
 
 
 def _p(t, name, dtype=f32):

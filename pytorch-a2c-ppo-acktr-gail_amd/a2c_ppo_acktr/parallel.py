@@ -123,7 +123,9 @@ class PiecewiseGraph(object):
     def capture(self, dp, body):
         import gc
         torch.cuda.synchronize(self.device)
-        gc.collect()                                    # nothing may be freed by the collector mid-capture
+        gc.collect()                                    # nothing may be freed by the collector mid-capture (see
+        gc_was_on = gc.isenabled()                      # ops.graph_capture): collect now, then keep it off
+        gc.disable()
         cur = torch.cuda.current_stream(self.device)
         self._stream = torch.cuda.Stream(device=self.device)
         self._stream.wait_stream(cur)
@@ -137,6 +139,8 @@ class PiecewiseGraph(object):
                     self._end()
         finally:
             dp._piecewise = None
+            if gc_was_on:
+                gc.enable()
         cur.wait_stream(self._stream)
         return self
 
@@ -166,6 +170,18 @@ def bounded_sync(device, seconds, what):
             sys.stderr.flush()
             os._exit(70)
         time.sleep(0.0005)
+
+
+def quiesce_collectives(device, seconds=0.35):
+    """Call before capturing RCCL collectives into a hipGraph (ACKTR_DP_GRAPH=full).  torch's process-group watchdog polls
+    the end events of the eager collectives it has not yet retired (every 100 ms); on HIP, querying an event whose stream
+    has MEANWHILE entered capture -- RCCL's stream joins ours through the capture's event edges -- fails with "operation
+    not permitted on an event last recorded in a capturing stream" and the watchdog takes the process down (seen once in
+    three runs of tests/test_dp_gpu.py).  So: let the device finish, then give the watchdog time for two polls, after which
+    it holds nothing recorded on that stream; collectives issued during capture are not handed to it."""
+    import time
+    torch.cuda.synchronize(device)
+    time.sleep(seconds)
 
 
 class _Done(object):

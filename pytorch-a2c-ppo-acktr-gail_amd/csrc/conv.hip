@@ -4,6 +4,7 @@
 //   8x8 stride 4 on 84x84, 4x4 stride 2 on 20x20, 3x3 stride 1 on 9x9 (any channel counts).
 #include "conv_ops.hpp"
 #include "conv_sw.hpp"
+#include "conv3_dgrad_oa.hpp"
 #include "conv_wgrad_sa.hpp"
 #include "../../include/acktr_hip.h"
 
@@ -302,10 +303,16 @@ static long sw_dgrad_image_floats(int geom, int OC) {
     return geom == GEOM_4S2 ? SwD2::image_floats() : SwD3::image_floats();
 }
 static long sw_dgrad_pad_floats(int geom, int B, int OC) { return (long)B * OC * 121 + 4; }
+// conv3's input gradient in overlap-add form (conv3_dgrad_oa.hpp) instead of the gather over the zero-padded dY:
+// NatureCNN's own channel counts only; ACKTR_D3_OA=0 keeps the gather kernel (same-box comparisons)
+static bool d3_oa(int geom, int C, int OC) {
+    static const bool on = []() { const char* ev = getenv("ACKTR_D3_OA"); return !ev || atoi(ev) != 0; }();
+    return on && geom == GEOM_3S1 && C == OA_CI && OC == OA_CO;
+}
 
 // Several weight images in ONE launch (blockIdx.y = job): inside a captured graph every dependent launch costs
 // ~4.5 us, more than any of these packs takes.
-enum { PK_F1, PK_F2, PK_F3, PK_D3, PK_D2 };
+enum { PK_F1, PK_F2, PK_F3, PK_D3, PK_D2, PK_D3OA };
 struct SwPackJob { const float* w; float* img; int kind, M, mode, CX, SD; };
 constexpr int SW_PACK_MAX_JOBS = 8;
 struct SwPackJobs { SwPackJob j[SW_PACK_MAX_JOBS]; };
@@ -316,6 +323,7 @@ __global__ __launch_bounds__(256) void sw_pack_multi_kernel(SwPackJobs jobs) {
         case PK_F2: sw_pack_body<SwF2>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
         case PK_F3: sw_pack_body<SwF3>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
         case PK_D3: sw_pack_body<SwD3>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
+        case PK_D3OA: oa_pack_body(jb.w, jb.img); break;
         default: sw_pack_body<SwD2>(jb.w, jb.img, jb.M, jb.mode, jb.CX, jb.SD); break;
     }
 }
@@ -518,6 +526,7 @@ extern "C" long acktr_conv2d_dgrad_workspace_bytes(int B, int C, int H, int W, i
 extern "C" long acktr_conv2d_dgrad_padded_dy_offset_bytes(int C, int H, int W, int OC, int KH, int KW, int S) {
     const int geom = geom_of(H, W, KH, KW, S);
     if (geom == GEOM_NONE || !sw_dgrad_ok(geom, C, OC)) return -1;
+    if (d3_oa(geom, C, OC)) return -1;                 // the overlap-add kernel reads dY as it is
     return sw_dgrad_image_floats(geom, OC) * (long)sizeof(float);
 }
 
@@ -555,6 +564,18 @@ extern "C" int acktr_conv2d_dgrad_carry_f32(const float* dy, const float* w, con
     ACKTR_ARG(((uintptr_t)workspace & 15) == 0, "conv2d_dgrad: workspace must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     float* wp = (float*)workspace;
+    if (d3_oa(geom, C, OC) && sw_dgrad_ok(geom, C, OC) && (long)B * C * 121 < (1L << 31)) {
+        ACKTR_ARG(dy && !prepadded, "conv2d_dgrad: this shape reads dY unpadded (acktr_conv2d_dgrad_padded_dy_offset_bytes says so)");
+        static_assert(OA_IMG_FLOATS <= SwD3::IMAGE_FLOATS, "the overlap-add image lives in the gather kernel's slot");
+        if (!prepacked) {
+            hipLaunchKernelGGL(sw_pack_multi_kernel, dim3((OA_IMG_FLOATS + 255) / 256, 1), dim3(256), 0, s,
+                               SwPackJobs{{{w, wp, PK_D3OA, 0, 0, 0, 0}}});
+            ACKTR_LAUNCH_CHECK();
+        }
+        const int pw = W + 2 * pad;
+        if (x_act) return launch_conv3_dgrad_oa<true>(dy, wp, x_act, dx, dx_padded, pw, (H + 2 * pad) * pw, pad * pw + pad, B, s, carry);
+        return launch_conv3_dgrad_oa<false>(dy, wp, nullptr, dx, dx_padded, pw, (H + 2 * pad) * pw, pad * pw + pad, B, s, carry);
+    }
     if (sw_dgrad_ok(geom, C, OC) && (long)B * OC * 121 < (1L << 31)) {
         float* img = wp;
         float* dyp = wp + sw_dgrad_image_floats(geom, OC);
@@ -626,6 +647,7 @@ extern "C" int acktr_conv2d_pack_weights_f32(const acktr_conv_pack_job* jobs, in
             o.mode = 1;
             o.CX = jb.C;
             if (geom == GEOM_4S2) { o.kind = PK_D2; o.M = 4 * jb.C; o.SD = 2; }
+            else if (d3_oa(geom, jb.C, jb.OC)) { o.kind = PK_D3OA; img_floats = OA_IMG_FLOATS; }
             else { o.kind = PK_D3; o.M = jb.C; o.SD = 1; }
         }
         if (img_floats > biggest) biggest = img_floats;

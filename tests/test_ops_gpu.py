@@ -51,6 +51,31 @@ def test_conv2d_fwd_wgrad_dgrad(H, K, S, B, C, OC):
     assert rel(dxg * scale, xr.grad * (x > 0).float()) < TOL
 
 
+@pytest.mark.parametrize('B', [1, 2, 3, 7, 80, 513, 640, 1024, 1031])
+def test_conv3_dgrad_overlap_add(B):
+    """NatureCNN's conv3 input gradient (64 <- 32 channels, 3x3 s1, 9x9 <- 7x7) runs in overlap-add form
+    (csrc/conv3_dgrad_oa.hpp): image ranges of 1-5 images per wave, tiles that straddle images, the ring of two LDS image
+    slots, the gate, the zero-padded second copy for the conv2 dgrad, and the same result twice (fixed summation order)."""
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(900 + B)
+    dy = torch.randn(B, 32, 7, 7, generator=g)
+    w = torch.randn(32, 64, 3, 3, generator=g) / 24.0
+    xact = torch.relu(torch.randn(B, 64, 9, 9, generator=g))
+    ref = F.conv_transpose2d(dy.double(), w.double()).float()
+    dyd, wd, xd = dy.cuda(), w.cuda(), xact.cuda()
+    dx = ops.conv2d_dgrad(dyd, wd, None, 1)
+    assert rel(dx, ref) < TOL
+    pad = torch.full((B, 64, 11, 11), 7.0, device='cuda')
+    dxg = ops.conv2d_dgrad(dyd, wd, xd, 1, padded_out=pad)
+    refg = ref * (xact > 0).float()
+    assert rel(dxg, refg) < TOL
+    assert torch.equal(pad[:, :, 1:10, 1:10], dxg), 'padded copy = the same values, interior only'
+    assert bool((pad[:, :, 0, :] == 7.0).all()) and bool((pad[:, :, :, 10] == 7.0).all()), 'borders are not written'
+    assert torch.equal(dxg == 0, (xd <= 0) | (dxg == 0))
+    dxg2 = ops.conv2d_dgrad(dyd, wd, xd, 1)
+    assert torch.equal(dxg, dxg2), 'run-to-run deterministic'
+
+
 def test_conv1_gather_fused():
     from a2c_ppo_acktr import ops
     g = torch.Generator().manual_seed(11)

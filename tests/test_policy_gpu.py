@@ -501,7 +501,8 @@ def test_folded_dgrad_padding_is_bit_identical(B):
                                      old_values=vp, returns=ret, adv=adv, clip=0.1, value_coef=0.5, entropy_coef=0.01,
                                      gflat=gflat)
                     engine.backward(pol, acts, gflat, keep=True)
-                assert (acts.pd3 is not None) == fold and (acts.pd2 is not None) == fold
+                # (pd3 stays None when conv3's dgrad reads dY unpadded: the overlap-add kernel)
+                assert (acts.pd2 is not None) == fold and (fold or acts.pd3 is None)
                 res.append((gflat.clone(), acts.dy1.clone(), acts.dy2.clone()))
             finally:
                 engine.FOLD_PAD = True
@@ -556,3 +557,35 @@ def test_captured_graph_survives_workspace_growth():
         ops._ws_cache.clear()
     assert l_eager == l_graph
     assert torch.equal(p_eager, p_graph)
+
+
+def test_graph_capture_keeps_the_garbage_collector_out():
+    """ops.graph_capture: Python's cyclic collector is off while a hipGraph is being captured (a collection that runs then
+    can finalise a dropped agent's CUDAGraph, whose destructor aborts the process under capture) and back on afterwards;
+    workspaces hand out exactly the bytes asked for (split-K slab counts must not depend on what ran before)."""
+    import gc
+    from a2c_ppo_acktr import ops
+
+    class Cycle(object):                       # an unreachable cycle that owns a captured graph, like a dropped agent
+        def __init__(self):
+            self.me = self
+            self.g = torch.cuda.CUDAGraph()
+            self.x = torch.zeros(8, device='cuda')
+            with ops.graph_capture(self.g):
+                self.x += 1
+    Cycle()
+    assert gc.isenabled()
+    x = torch.zeros(1024, device='cuda')
+    g = torch.cuda.CUDAGraph()
+    with ops.graph_capture(g):
+        assert not gc.isenabled()
+        junk = [[i] for i in range(100000)]    # enough allocations for several generation-0 collections
+        del junk
+        x += 1
+    assert gc.isenabled()
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(x.sum()) == 1024.0
+    big = ops.workspace(x.device, 3 << 20, 'gc_test')
+    small = ops.workspace(x.device, 4096, 'gc_test')
+    assert big.numel() == 3 << 20 and small.numel() == 4096 and small.data_ptr() == big.data_ptr()

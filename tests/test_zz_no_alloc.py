@@ -2,6 +2,8 @@
 acktr_adv_normalize_f32, straight through the C-ABI.  Same kernels, same fixed-order reduction -> bit-identical.
 Two calls in a row share the library's per-GPU scratch array; the second uses a smaller input.  Collected last
 (file name), so a failure here cannot hide another test under `pytest -x`."""
+import gc
+
 import pytest
 import torch
 
@@ -25,13 +27,22 @@ def _both(n, seed):
     torch.cuda.synchronize()
     # hipMemGetInfo sees every allocation on the device, the library's own hipMalloc / hipFree included (torch's
     # memory_allocated() only counts torch's caching allocator)
-    free_before, _ = torch.cuda.mem_get_info(dev)
-    before = torch.cuda.memory_allocated(dev)
-    _hip.check(L.acktr_adv_normalize_noalloc_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(got), n, stream),
-               'acktr_adv_normalize_noalloc_f32')
-    torch.cuda.synchronize()
-    assert torch.cuda.memory_allocated(dev) == before
-    assert torch.cuda.mem_get_info(dev)[0] == free_before, 'device memory was allocated or freed inside the call'
+    # (Python's cyclic collector is kept out of the measured region: a collection that happens to run there frees dead
+    #  tensors of EARLIER tests and moves both counters)
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        free_before, _ = torch.cuda.mem_get_info(dev)
+        before = torch.cuda.memory_allocated(dev)
+        _hip.check(L.acktr_adv_normalize_noalloc_f32(_hip.dev_ptr(ret), _hip.dev_ptr(val), _hip.dev_ptr(got), n, stream),
+                   'acktr_adv_normalize_noalloc_f32')
+        torch.cuda.synchronize()
+        assert torch.cuda.memory_allocated(dev) == before
+        assert torch.cuda.mem_get_info(dev)[0] == free_before, 'device memory was allocated or freed inside the call'
+    finally:
+        if gc_was_on:
+            gc.enable()
     return want, got
 
 

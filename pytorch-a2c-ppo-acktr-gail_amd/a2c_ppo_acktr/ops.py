@@ -87,8 +87,8 @@ def graph_capture(g, **kw):
     which answers "operation not permitted when stream is capturing", and torch aborts the process from the destructor
     (seen once in the GPU suite, inside the GAIL step's capture)."""
     was_enabled = gc.isenabled()
-    gc.collect()
-    gc.disable()
+    gc.disable()                # (torch.cuda.graph collects explicitly on entry; a second full collection here cost the
+                                #  bench's ACKTR loop, whose capture falls into its timed updates, 110 ms)
     try:
         with torch.cuda.graph(g, **kw):
             yield g

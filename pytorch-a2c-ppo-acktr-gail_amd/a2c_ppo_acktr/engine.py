@@ -41,16 +41,41 @@ def dist_linear(policy):
     return policy.dist.linear if policy.dist.kind == 0 else policy.dist.fc_mean
 
 
-def cnn_layer_params(policy):
+def _per_layout(policy, what, build):
+    """`build(policy)` once per parameter layout.  Walking the module tree (nn.Module.__getattr__, Sequential indexing) for
+    the same twelve parameters eight times per minibatch step was a quarter of the host time of an eager (data-parallel)
+    PPO step.  The layout changes exactly when Policy rebuilds its offset table (to(), unpickling, KFAC's split_bias ->
+    rebind_flat): the cache is keyed on that table's identity."""
+    d = policy.__dict__
+    offs = d.get('_offsets')
+    c = d.get('_lp_cache')
+    if c is None or c[0] is not offs:
+        c = d['_lp_cache'] = (offs, {})
+    r = c[1].get(what)
+    if r is None:
+        r = c[1][what] = build(policy)
+    return r
+
+
+def _cnn_layer_params(policy):
     m = policy.base.main
     return {'conv1': _wb(m[0]), 'conv2': _wb(m[2]), 'conv3': _wb(m[4]), 'fc': _wb(m[7]),
             'critic': _wb(policy.base.critic_linear), 'actor': _wb(dist_linear(policy))}
 
 
-def mlp_layer_params(policy):
+def cnn_layer_params(policy):
+    """{'conv1': (weight, bias), ...} of a CNNBase policy (read-only: shared between calls)."""
+    return _per_layout(policy, 'cnn', _cnn_layer_params)
+
+
+def _mlp_layer_params(policy):
     b = policy.base
     return {'a0': _wb(b.actor[0]), 'a2': _wb(b.actor[2]), 'c0': _wb(b.critic[0]), 'c2': _wb(b.critic[2]),
             'critic': _wb(b.critic_linear), 'mean': _wb(dist_linear(policy))}
+
+
+def mlp_layer_params(policy):
+    return _per_layout(policy, 'mlp', _mlp_layer_params)
 
 
 def logstd_param(policy):
@@ -109,12 +134,12 @@ def _check_input(policy, inputs, gather_idx):
 
 def head_views(policy, flat):
     """[1+A, hidden] weight and [1+A] bias views of the fused CNN head inside a flat buffer."""
-    L = cnn_layer_params(policy)
-    wc, bc = L['critic']
-    wa, ba = L['actor']
-    ow, _ = policy._offsets[id(wc)]
-    ob, _ = policy._offsets[id(bc)]
-    hidden, A = wc.shape[1], wa.shape[0]
+    def where(policy):
+        L = cnn_layer_params(policy)
+        wc, bc = L['critic']
+        wa, ba = L['actor']
+        return policy._offsets[id(wc)][0], policy._offsets[id(bc)][0], wc.shape[1], wa.shape[0]
+    ow, ob, hidden, A = _per_layout(policy, 'head', where)
     return (flat[ow:ow + (1 + A) * hidden].view(1 + A, hidden), flat[ob:ob + 1 + A])
 
 

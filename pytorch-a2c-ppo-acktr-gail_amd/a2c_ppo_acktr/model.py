@@ -113,7 +113,7 @@ class Policy(nn.Module):
 
     # checkpoints: the reference pickles the whole module (main.py:165-176, enjoy.py:52-54).  The flat buffers and
     # the id()-keyed offset table are derived state: they are left out of the pickle and rebuilt from the parameters.
-    _DERIVED = ('flat_params', 'flat_grads', '_offsets', '_pack_ws')
+    _DERIVED = ('flat_params', 'flat_grads', '_offsets', '_pack_ws', '_lp_cache')
 
     def __getstate__(self):
         state = self.__dict__.copy()

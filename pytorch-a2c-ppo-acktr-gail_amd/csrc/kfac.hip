@@ -417,11 +417,19 @@ extern "C" int acktr_kfac_cov_g_conv_f32(const float* dy, int B, int OC, int SP,
     return -1;
 }
 
+static int cov_dense_sa(const float* a, long lda, int B, int D, float alpha, float* out, hipStream_t s);
+
 extern "C" int acktr_kfac_cov_dense_f32(const float* a, long lda, int B, int D, float alpha, float* out,
                                         void* workspace, long workspace_bytes, void* stream) {
     ACKTR_ARG(a && out, "kfac_cov_dense: null pointer");
     ACKTR_ARG(B > 0 && D > 0 && lda >= D, "kfac_cov_dense: bad sizes");
     hipStream_t s = (hipStream_t)stream;
+    // wide factors (the FC layer's 1568 x 1568 input factor, the 512 x 512 ones): upper-triangle 64 x 64 tiles on
+    // stationary accumulators, both operands read straight along the feature index (precond_sa_kernel below) -- the tile
+    // GEMM ran the 1568 factor at 22 TFLOP/s (60 us + a slab sum)
+    static const bool sa_off = getenv("ACKTR_COV_DENSE_TILE") != nullptr;      // comparison switch
+    // (measured at 640 rows: D = 1568 69.7 -> 47 us; D = 512 and 256 are quicker on the tile GEMM: 18.9 / 14.3 against 24.0 / 22.7 us)
+    if (!sa_off && D >= 1024 && B >= 64 && lda < (1L << 30)) return cov_dense_sa(a, lda, B, D, alpha, out, s);
     float* ws = (float*)workspace;
     const long wf = workspace ? workspace_bytes / (long)sizeof(float) : 0;
     const long tiles = (long)cdiv(D, 128) * cdiv(D, 128);
@@ -742,6 +750,8 @@ constexpr int PS_WAVES = 8, PS_PITCH = 65, PS_LDS_BYTES = PS_WAVES * 64 * PS_PIT
 struct PsJob {
     const float* a; const float* b; float* c; const float* div_m; const float* div_n;
     int M, N, K, lda, ldb, ldc, tile0, tiles_n, v2, transposed;
+    int upper;        // symmetric product (a == b, M == N): only the tiles on and above the diagonal, row by row
+    float scale;
 };
 struct PsJobs { PsJob j[GROUP_MAX]; int count; float div_add; };
 
@@ -754,8 +764,14 @@ __global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) 
     const PsJob& J = jobs.j[z];
     // (plain tile order: dealing a layer's column tiles to the XCDs as fc_wgrad_sa_kernel does measured SLOWER here --
     //  45 / 100 us against 30 / 77 us for the 0.8 / 2.5 GFLOP stages of the 512 x 1568 layer)
-    const int t = blockIdx.x - J.tile0;
-    const int m0 = (t / J.tiles_n) * 64, n0 = (t % J.tiles_n) * 64;
+    int t = blockIdx.x - J.tile0;
+    int tm = t / J.tiles_n, tn = t % J.tiles_n;
+    if (J.upper) {                                                             // (uniform) row tm holds tiles tm .. tiles_n - 1
+        tm = 0;
+        while (t >= J.tiles_n - tm) { t -= J.tiles_n - tm; ++tm; }
+        tn = tm + t;
+    }
+    const int m0 = tm * 64, n0 = tn * 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
     const int M = J.M, N = J.N, K = J.K, lda = J.lda, ldb = J.ldb;
     const bool V2 = J.v2 != 0;
@@ -838,7 +854,24 @@ __global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) 
         const int m = m0 + ml, n = n0 + nl;
         if (m < M && n < N) {
             if (J.div_m) sum = sum / (J.div_m[m] * J.div_n[n] + jobs.div_add);
+            else sum = sum * J.scale;
             if (tr) J.c[(long)n * J.ldc + m] = sum; else J.c[(long)m * J.ldc + n] = sum;
+        }
+    }
+    // symmetric product: a tile above the diagonal is also its mirror image below it -- the same sums (same order, so
+    // bit-identical), stored along the other index so that these stores are coalesced too; no separate mirror launch
+    if (J.upper && tm != tn) {
+        for (int e = threadIdx.x; e < 4096; e += 64 * PS_WAVES) {
+            const int ml = e & 63, nl = e >> 6;
+            const int a = V2 ? (ml & 1) : (ml >> 5), i = V2 ? (ml >> 1) : (ml & 31);
+            const int b = V2 ? (nl & 1) : (nl >> 5), jn = V2 ? (nl >> 1) : (nl & 31);
+            const int v = (i & 3) | ((i >> 3) << 2), l = (((i >> 2) & 1) << 5) | jn;
+            const int off = ((a * 2 + b) * 16 + v) * PS_PITCH + l;
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < PS_WAVES; ++w) sum += ps_smem[w * (64 * PS_PITCH) + off];
+            const int m = m0 + ml, n = n0 + nl;
+            if (m < M && n < N) J.c[(long)n * J.ldc + m] = sum * J.scale;
         }
     }
 }
@@ -858,7 +891,7 @@ static int precondition_sa_group(const acktr_precond_job* jb, int n, float dampi
         for (int i = 0; i < n; ++i) {
             const acktr_precond_job& J = jb[i];
             PsJob& P = jobs.j[i];
-            P.M = J.OUT; P.N = J.IN; P.div_m = nullptr; P.div_n = nullptr;
+            P.M = J.OUT; P.N = J.IN; P.div_m = nullptr; P.div_n = nullptr; P.upper = 0; P.scale = 1.f;
             switch (stage) {
                 case 0: P.a = J.q_g; P.lda = J.OUT; P.b = J.grad; P.ldb = J.IN; P.K = J.OUT; P.c = J.tmp1; P.transposed = 1; break;
                 case 1: P.a = J.tmp1; P.lda = J.OUT; P.b = J.q_a; P.ldb = J.IN; P.K = J.IN; P.c = J.tmp2; P.transposed = 0;
@@ -878,6 +911,28 @@ static int precondition_sa_group(const acktr_precond_job* jb, int n, float dampi
     return 0;
 }
 }  // namespace acktr
+
+// out[i, j] = alpha * sum_b a[b, i] a[b, j] (kfac.py:38-46 for a Linear layer's input / grad-output rows) on the same kernel
+static int cov_dense_sa(const float* a, long lda, int B, int D, float alpha, float* out, hipStream_t s) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(acktr::precond_sa_kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, acktr::PS_LDS_BYTES);
+        if (e != hipSuccess) { set_error("cov_dense_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+        attr_set = true;
+    }
+    acktr::PsJobs jobs;
+    jobs.count = 1; jobs.div_add = 0.f;
+    acktr::PsJob& P = jobs.j[0];
+    P.a = a; P.b = a; P.c = out; P.div_m = nullptr; P.div_n = nullptr;
+    P.M = D; P.N = D; P.K = B; P.lda = (int)lda; P.ldb = (int)lda; P.ldc = D; P.tile0 = 0; P.tiles_n = cdiv(D, 64);
+    P.v2 = (D % 2 == 0 && lda % 2 == 0 && (((uintptr_t)a) & 7) == 0) ? 1 : 0;
+    P.transposed = 0; P.upper = 1; P.scale = alpha;
+    const int tiles = P.tiles_n * (P.tiles_n + 1) / 2;
+    hipLaunchKernelGGL(acktr::precond_sa_kernel, dim3(tiles), dim3(64 * acktr::PS_WAVES), acktr::PS_LDS_BYTES, s, jobs);
+    ACKTR_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int acktr_kfac_precondition_batched_f32(const acktr_precond_job* jobs, int count, float damping, void* stream) {
     ACKTR_ARG(jobs && count > 0, "kfac_precondition_batched: no jobs");

@@ -755,26 +755,16 @@ struct PsJob {
 };
 struct PsJobs { PsJob j[GROUP_MAX]; int count; float div_add; };
 
-__global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) {
+// (V2 as a template parameter, chosen once per workgroup at the top of the kernel: with the flag tested inside the K loop's
+//  load block the compiler could not interleave loads and MFMAs across the branch -- the 2.5 GFLOP stages of the 512 x 1568
+//  layer ran 66 us here against 43 us for the same product in fc_wgrad_sa_kernel)
+template <bool V2>
+__device__ __forceinline__ void ps_tile(const PsJob& J, const float div_add, const int tm, const int tn, float* ps_smem) {
     typedef float ps2 __attribute__((ext_vector_type(2)));
     typedef ps2 ps2u __attribute__((aligned(8)));
-    extern __shared__ __attribute__((aligned(16))) float ps_smem[];           // [wave][blk 4][reg 16][PS_PITCH]
-    int z = 0;
-    while (z + 1 < jobs.count && (int)blockIdx.x >= jobs.j[z + 1].tile0) ++z;  // (uniform)
-    const PsJob& J = jobs.j[z];
-    // (plain tile order: dealing a layer's column tiles to the XCDs as fc_wgrad_sa_kernel does measured SLOWER here --
-    //  45 / 100 us against 30 / 77 us for the 0.8 / 2.5 GFLOP stages of the 512 x 1568 layer)
-    int t = blockIdx.x - J.tile0;
-    int tm = t / J.tiles_n, tn = t % J.tiles_n;
-    if (J.upper) {                                                             // (uniform) row tm holds tiles tm .. tiles_n - 1
-        tm = 0;
-        while (t >= J.tiles_n - tm) { t -= J.tiles_n - tm; ++tm; }
-        tn = tm + t;
-    }
     const int m0 = tm * 64, n0 = tn * 64;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, li = lane & 31, kh = lane >> 5;
     const int M = J.M, N = J.N, K = J.K, lda = J.lda, ldb = J.ldb;
-    const bool V2 = J.v2 != 0;
     const int per = ((K + 2 * PS_WAVES - 1) / (2 * PS_WAVES)) * 2;
     const int k0 = wave * per, k1 = min(K, k0 + per);
     const int mc0 = V2 ? m0 + 2 * li : m0 + li, mc1 = V2 ? mc0 + 1 : mc0 + 32;
@@ -797,7 +787,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) 
             const int kk = k + 2 * u + kh;
             const bool ok = kk < k1;
             const long ra = (long)(ok ? kk : 0) * lda, rb = (long)(ok ? kk : 0) * ldb;
-            if (V2) {                                                          // (uniform; pairs are whole: M, N, m0, n0 even)
+            if constexpr (V2) {                                                // (pairs are whole: M, N, m0, n0 even)
                 const ps2 a2 = (ok && mok0) ? *reinterpret_cast<const ps2u*>(ap + ra) : ps2{0.f, 0.f};
                 const ps2 b2 = (ok && nok0) ? *reinterpret_cast<const ps2u*>(bp + rb) : ps2{0.f, 0.f};
                 av[buf][u][0] = a2[0]; av[buf][u][1] = a2[1];
@@ -853,7 +843,7 @@ __global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) 
         for (int w = 0; w < PS_WAVES; ++w) sum += ps_smem[w * (64 * PS_PITCH) + off];
         const int m = m0 + ml, n = n0 + nl;
         if (m < M && n < N) {
-            if (J.div_m) sum = sum / (J.div_m[m] * J.div_n[n] + jobs.div_add);
+            if (J.div_m) sum = sum / (J.div_m[m] * J.div_n[n] + div_add);
             else sum = sum * J.scale;
             if (tr) J.c[(long)n * J.ldc + m] = sum; else J.c[(long)m * J.ldc + n] = sum;
         }
@@ -874,6 +864,24 @@ __global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) 
             if (m < M && n < N) J.c[(long)n * J.ldc + m] = sum * J.scale;
         }
     }
+}
+
+__global__ __launch_bounds__(64 * PS_WAVES) void precond_sa_kernel(PsJobs jobs) {
+    extern __shared__ __attribute__((aligned(16))) float ps_smem[];           // [wave][blk 4][reg 16][PS_PITCH]
+    int z = 0;
+    while (z + 1 < jobs.count && (int)blockIdx.x >= jobs.j[z + 1].tile0) ++z;  // (uniform)
+    const PsJob& J = jobs.j[z];
+    // (plain tile order: dealing a layer's column tiles to the XCDs as fc_wgrad_sa_kernel does measured SLOWER here --
+    //  45 / 100 us against 30 / 77 us for the 0.8 / 2.5 GFLOP stages of the 512 x 1568 layer)
+    int t = blockIdx.x - J.tile0;
+    int tm = t / J.tiles_n, tn = t % J.tiles_n;
+    if (J.upper) {                                                             // (uniform) row tm holds tiles tm .. tiles_n - 1
+        tm = 0;
+        while (t >= J.tiles_n - tm) { t -= J.tiles_n - tm; ++tm; }
+        tn = tm + t;
+    }
+    if (J.v2) ps_tile<true>(J, jobs.div_add, tm, tn, ps_smem);
+    else ps_tile<false>(J, jobs.div_add, tm, tn, ps_smem);
 }
 
 static int precondition_sa_group(const acktr_precond_job* jb, int n, float damping, hipStream_t s) {

@@ -154,7 +154,23 @@ static int conv1_wgrad_sa(const XT* x, const int64_t* idx, const float* dy, floa
         if (e != hipSuccess) { set_error("conv1_wgrad_sa: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
         attr_set = true;
     }
-    hipLaunchKernelGGL(conv1_wgrad_sa_kernel<XT>, dim3(ns), dim3(64 * S1_WAVES), S1_LDS_BYTES, s, x, idx, dy, ws, slab, B, scale);
+    // ACKTR_C1W=0 (tuning / comparison switch): the register-direct kernel.  Default: the LDS-ring kernel, 67.0 against 78.1 us
+    // inside the PPO step on float frames.  Byte frames take it too although the register-direct form is a little faster
+    // there (61.8 against 64.4 us: a byte frame is a quarter of the lines): one summation order for both storage types keeps
+    // the gradients of a byte-frame run bit-identical to the float-frame run's (tests/test_u8_gpu.py).
+    static const bool ring = [] { const char* v = getenv("ACKTR_C1W"); return !(v && v[0] == '0'); }();
+    if (ring && (((uintptr_t)x) & 15) == 0) {
+        static bool attr9_set = false;
+        if (!attr9_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv1_wgrad_ring_kernel<XT>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, S9_LDS_BYTES);
+            if (e != hipSuccess) { set_error("conv1_wgrad_ring: hipFuncSetAttribute failed: %s", hipGetErrorString(e)); return (int)e; }
+            attr9_set = true;
+        }
+        hipLaunchKernelGGL(conv1_wgrad_ring_kernel<XT>, dim3(ns), dim3(64 * S9_WAVES), S9_LDS_BYTES, s, x, idx, dy, ws, slab, B, scale);
+    } else {
+        hipLaunchKernelGGL(conv1_wgrad_sa_kernel<XT>, dim3(ns), dim3(64 * S1_WAVES), S1_LDS_BYTES, s, x, idx, dy, ws, slab, B, scale);
+    }
     ACKTR_LAUNCH_CHECK();
     if (defer && db == dw + wk && ns >= 16 && (((uintptr_t)dw | (uintptr_t)ws) & 15) == 0) {   // (what slab_reduce_wave_kernel serves)
         defer->dst = dw; defer->slabs = ws; defer->nslabs = ns; defer->n4 = (wk + S1_OC) / 4; defer->stride = slab;

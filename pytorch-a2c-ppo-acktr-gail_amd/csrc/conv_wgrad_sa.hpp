@@ -275,6 +275,193 @@ __global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const XT*
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// Second form (round 3, the default for float frames): ALL 256 taps in one wave -- eight 32x32 tiles, 128 accumulator
+// registers; lane (li, h) stands for the frame row (c = li/8, ky = li%8) and tile q for kx = q, so position s and tap kx read
+// float 4s + kx of the lane's run -- and the frames go through a PRIVATE LDS ring of the wave.  What limits the kernel
+// above is not bytes but cache-line look-ups: a lane stands for a frame row, so one 16-byte load instruction touches
+// 32-64 different 128-byte lines, and the two kx halves of a tile side sit in neighbouring lanes, so every frame float
+// goes through the vector memory path four times (512 MB per launch at B = 1024).  An intermediate form (eight tiles per
+// wave, register-direct loads, one wave per SIMD) loaded each float twice and ran 72 us stand-alone against 84 -- with
+// its MFMAs removed still 51 us for 360 MB, ~27 B/clk per CU.  Here the unit of work is one OUTPUT ROW oy of one image (20 positions, 80 MFMAs per wave): it reads the
+// frame rows 4oy .. 4oy+7 of the four channels = the two "quads" oy and oy+1 (a quad = rows 4k .. 4k+3, 4 x 1344
+// contiguous bytes), and the next row re-uses quad oy+1.  A wave walks consecutive rows, so every step brings in ONE
+// new quad with fully coalesced 16-byte loads (eight lanes per line; 5.25 loads per lane), parks it in a register set for
+// one step (the latency budget), writes it to slot (step % 3) of its ring and reads its own 44 floats per lane from there
+// (eleven ds_read_b128).  Every frame float crosses the vector memory path once per workgroup: 115 MB per launch, as from
+// HBM.  No barrier in the loop (the ring is private), the compiler counts every load (all plain loads).  Steps: image b has
+// quads k = 0 .. 20; step (b, k) loads quad k and, for k >= 1, multiplies row oy = k - 1; global step gs = 21 b + k.
+// dY (A operand) stays a direct load: lane (oc, h) reads its 10 positions 10h .. 10h+9 of the row (16 + 16 + 8 bytes).
+constexpr int S9_WAVES = 8, S9_QF = 4 * 4 * S1_H, S9_QS = S9_QF + 32, S9_WAVE_FLOATS = 3 * S9_QS;
+constexpr int S9_LDS_BYTES = S9_WAVES * S9_WAVE_FLOATS * 4;
+static_assert(S9_LDS_BYTES >= (4 * 8 * 16 * 64 + S9_WAVES * 32) * 4, "the closing sums re-use the rings");
+struct S9A { f32x4 p0, p1; f32x2 p2; };
+__device__ __forceinline__ float s9_a(const S9A& a, int s) { return s < 4 ? a.p0[s] : (s < 8 ? a.p1[s - 4] : a.p2[s - 8]); }
+
+// XT = uint8_t: a quad is 4 x 336 bytes (84 pieces: two loads per lane), the ring holds bytes and a lane reads its 44 bytes
+// as eleven dwords; the bytes are converted (exactly) where the MFMA consumes them.
+template <class XT>
+__global__ __launch_bounds__(64 * S9_WAVES) void conv1_wgrad_ring_kernel(const XT* __restrict__ x, const int64_t* __restrict__ idx,
+                                                                        const float* __restrict__ dy, float* __restrict__ slabs,
+                                                                        long slab_stride, int B, float scale) {
+    constexpr bool U8 = std::is_same<XT, uint8_t>::value;
+    constexpr int NP = U8 ? 2 : 6;                               // 16-byte pieces per lane and quad (the last one partial)
+    constexpr int PIECES = U8 ? 84 : 336, CH_PIECES = PIECES / 4, LAST = PIECES - 64 * (NP - 1);
+    constexpr int SLOT = S9_QS * (int)sizeof(XT);                // bytes
+    extern __shared__ __attribute__((aligned(16))) float s9_lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int li = lane & 31, h = lane >> 5;
+    char* wl = reinterpret_cast<char*>(s9_lds + wave * S9_WAVE_FLOATS);
+    const long U = (long)B * 20;
+    const int R = gridDim.x * S9_WAVES, r = blockIdx.x * S9_WAVES + wave;
+    const int u0 = (int)(U * r / R), u1 = (int)(U * (r + 1) / R);
+
+    int poff[NP];                                              // piece 64 i + lane of a quad: [c][4 rows x 84 values], in values
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int pi = lane + 64 * i, pc = pi < PIECES ? pi : PIECES - 1;
+        poff[i] = (pc / CH_PIECES) * (S1_H * S1_H) + (pc % CH_PIECES) * (16 / (int)sizeof(XT));
+    }
+    const int rowoff = (((li >> 3) * 4 + (li & 3)) * S1_H + 40 * h) * (int)sizeof(XT);   // the lane's 44 values inside a slot (bytes)
+    const bool upper = (li & 7) >= 4;                                  // frame rows ky >= 4 lie in the step's own quad
+    const int aoff = li * S1_SP + 10 * h;
+
+    f32x16 acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[q][i] = 0.f;
+    float bsum = 0.f;
+
+    struct __attribute__((packed, aligned(8))) F4 { f32x4 v; };
+    u32x4 st[NP];
+    auto issue_quad = [&](int gs) {
+        const int b = gs / 21, k = gs - b * 21;
+        const long img = idx ? idx[b] : (long)b;
+        const XT* src = x + img * (S1_C * S1_H * S1_H) + k * (4 * S1_H);
+#pragma unroll
+        for (int i = 0; i < NP - 1; ++i) st[i] = *reinterpret_cast<const u32x4*>(src + poff[i]);
+        if (lane < LAST) st[NP - 1] = *reinterpret_cast<const u32x4*>(src + poff[NP - 1]);
+    };
+    auto write_quad = [&](int gs) {
+        char* dst = wl + (gs % 3) * SLOT + 16 * lane;
+#pragma unroll
+        for (int i = 0; i < NP - 1; ++i) *reinterpret_cast<u32x4*>(dst + 1024 * i) = st[i];
+        if (lane < LAST) *reinterpret_cast<u32x4*>(dst + 1024 * (NP - 1)) = st[NP - 1];
+    };
+    auto load_a = [&](int gs) {                                 // dY of the row step gs multiplies (k = 0: row 0, not used)
+        const int b = gs / 21, k = gs - b * 21;
+        const float* p = dy + (long)b * (S1_OC * S1_SP) + (k > 0 ? k - 1 : 0) * 20 + aoff;
+        S9A a;
+        a.p0 = reinterpret_cast<const F4*>(p)->v;
+        a.p1 = reinterpret_cast<const F4*>(p + 4)->v;
+        a.p2 = *reinterpret_cast<const f32x2*>(p + 8);
+        return a;
+    };
+    if (u0 < u1) {
+        const int ul = u1 - 1;
+        const int gs0 = (u0 / 20) * 21 + u0 % 20, gsl = (ul / 20) * 21 + ul % 20 + 1;
+        issue_quad(gs0);
+        write_quad(gs0);
+        issue_quad(gs0 + 1);                                    // (gs0 + 1 <= gsl: the range holds at least one row)
+        S9A nxt = load_a(gs0 + 1);
+        for (int gs = gs0 + 1; gs <= gsl; ++gs) {
+            const int k = gs % 21;
+            const S9A cur = nxt;
+            // the quad of this step arrives from its register set; then the set and the dY registers are re-filled
+            write_quad(gs);
+            {
+                const int gn = gs + 1 <= gsl ? gs + 1 : gsl;
+                issue_quad(gn);
+                nxt = load_a(gn);
+            }
+            if (k == 0) continue;                               // first quad of an image: nothing to multiply yet
+            const char* row = wl + ((upper ? gs : gs - 1) % 3) * SLOT + rowoff;
+            if constexpr (U8) {
+                unsigned pw[11];
+#pragma unroll
+                for (int w = 0; w < 11; ++w) pw[w] = *reinterpret_cast<const unsigned*>(row + 4 * w);
+#pragma unroll
+                for (int s2 = 0; s2 < 10; ++s2) {
+                    const float a = s9_a(cur, s2);
+                    bsum += a;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, (float)((pw[s2 + (q >> 2)] >> (8 * (q & 3))) & 0xffu), acc[q], 0, 0, 0);
+                }
+            } else {
+                // the lane's eleven 16-byte pieces in two batches (six now, five once pieces 0 .. 3 are dead)
+                f32x4 pc[11];
+#pragma unroll
+                for (int w = 0; w < 6; ++w) pc[w] = *reinterpret_cast<const f32x4*>(row + 16 * w);
+#pragma unroll
+                for (int s2 = 0; s2 < 10; ++s2) {
+                    const float a = s9_a(cur, s2);
+                    bsum += a;
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, pc[s2 + (q >> 2)][q & 3], acc[q], 0, 0, 0);
+                    if (s2 == 3) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int w = 6; w < 11; ++w) pc[w] = *reinterpret_cast<const f32x4*>(row + 16 * w);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            }
+        }
+    }
+    // fixed-order sum of the eight waves' partials: ((w0+w4) + (w2+w6)) + ((w1+w5) + (w3+w7)), through the (dead) rings
+    __syncthreads();
+    auto dump = [&](int slot) {
+        float* m = s9_lds + slot * (8 * 16 * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[(q * 16 + i) * 64 + lane] = acc[q][i];
+    };
+    auto add_in = [&](int slot) {
+        const float* m = s9_lds + slot * (8 * 16 * 64);
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][i] += m[(q * 16 + i) * 64 + lane];
+    };
+    {
+        const float t = bsum + __shfl_xor(bsum, 32);
+        if (h == 0) s9_lds[4 * 8 * 16 * 64 + wave * 32 + li] = t;
+    }
+    if (wave >= 4) dump(wave - 4);
+    __syncthreads();
+    if (wave < 4) add_in(wave);
+    __syncthreads();
+    if (wave == 2 || wave == 3) dump(wave - 2);
+    __syncthreads();
+    if (wave < 2) add_in(wave);
+    __syncthreads();
+    if (wave == 1) dump(0);
+    __syncthreads();
+    float* slab = slabs + (long)blockIdx.x * slab_stride;
+    if (wave == 0) {
+        add_in(0);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int oc = (i & 3) + 8 * (i >> 2) + 4 * h;
+            float* dst = slab + oc * S1_KC + li * 8;
+            f32x4 v0, v1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { v0[u] = acc[u][i] * scale; v1[u] = acc[4 + u][i] * scale; }
+            *reinterpret_cast<f32x4*>(dst) = v0;
+            *reinterpret_cast<f32x4*>(dst + 4) = v1;
+        }
+    } else if (wave == 1 && lane < 32) {
+        const float* bs = s9_lds + 4 * 8 * 16 * 64;
+        float t = bs[lane];
+#pragma unroll
+        for (int w = 1; w < S9_WAVES; ++w) t += bs[w * 32 + lane];
+        slab[S1_OC * S1_KC + lane] = t;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Stationary-accumulator weight gradient of the 4x4 stride-2 layer on 20x20x32 activations (reference model.py:177, its
 // autograd backward):  dW[oc, (c,ky,kx)] = scale * sum_{b,p} dY[b,oc,p] * X[b,c,2oy+ky,2ox+kx],  db[oc] = sum dY.
 // Same construction as conv1_wgrad_sa_kernel; what differs:

@@ -10,6 +10,8 @@ OPS = [('conv8s4_fwd', 'SwGeom<8, 8, 4, 84, 84, 4,'), ('conv4s2_fwd', 'SwGeom<4,
        ('conv3s1_fwd', 'SwGeom<3, 3, 1, 9, 9, 64,'), ('conv3s1_dgrad', 'SwGeom<3, 3, 1, 11, 11, 32,'),
        ('conv3s1_dgrad', 'conv3_dgrad_oa_kernel'),      # overlap-add form (csrc/conv3_dgrad_oa.hpp), the default
        ('conv4s2_dgrad', 'SwGeom<2, 2, 1, 11, 11, 64,'), ('conv8s4_wgrad', 'conv1_wgrad_sa_kernel'),
+       ('conv8s4_wgrad', 'conv1_wgrad_ring_kernel'),     # LDS-ring form (csrc/conv_wgrad_sa.hpp), the default for float frames
+      
        ('conv4s2_wgrad', 'conv2_wgrad_sa_kernel'), ('conv3s1_wgrad', 'conv3_wgrad_sa_kernel'),
        ('linear1568x512_fwd', 'DenseKCT<true>, acktr::DenseKCT<true>'),
        ('linear1568x512_wgrad', 'fc_wgrad_sa_kernel'),
@@ -20,7 +22,7 @@ f = {r['kernel']: r for r in csv.DictReader(open(sys.argv[1]))}
 w = {r['kernel']: r for r in csv.DictReader(open(sys.argv[2]))}
 out = {}
 for op, pat in OPS:
-    ks = [k for k in f if pat in k and ('conv_sw_kernel' in k or 'gemm_mfma' in k or 'wgrad_sa_kernel' in k or 'cov_a_' in k or 'dgrad_oa_kernel' in k)
+    ks = [k for k in f if pat in k and ('conv_sw_kernel' in k or 'gemm_mfma' in k or 'wgrad_sa_kernel' in k or 'wgrad_ring_kernel' in k or 'cov_a_' in k or 'dgrad_oa_kernel' in k)
           and 'reduce' not in k and 'mirror' not in k]
     if not ks or any(k not in w for k in ks):
         continue

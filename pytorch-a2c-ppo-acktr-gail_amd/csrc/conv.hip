@@ -673,3 +673,9 @@ extern "C" int acktr_conv2d_pack_weights_f32(const acktr_conv_pack_job* jobs, in
     ACKTR_LAUNCH_CHECK();
     return 0;
 }
+
+#ifdef S9_STAMP
+extern "C" int acktr_debug_s9_stamps(long long* host_out) {      // diagnostic build only (tools/probe/s9_clock.py)
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(acktr::s9_stamps), sizeof(long long) * 6 * 4096);
+}
+#endif

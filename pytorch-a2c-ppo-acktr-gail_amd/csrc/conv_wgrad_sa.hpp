@@ -294,6 +294,9 @@ __global__ __launch_bounds__(64 * S1_WAVES) void conv1_wgrad_sa_kernel(const XT*
 constexpr int S9_WAVES = 8, S9_QF = 4 * 4 * S1_H, S9_QS = S9_QF + 32, S9_WAVE_FLOATS = 3 * S9_QS;
 constexpr int S9_LDS_BYTES = S9_WAVES * S9_WAVE_FLOATS * 4;
 static_assert(S9_LDS_BYTES >= (4 * 8 * 16 * 64 + S9_WAVES * 32) * 4, "the closing sums re-use the rings");
+#ifdef S9_STAMP
+__device__ long long s9_stamps[6 * 4096];          // diagnostic build only: (loop cycles, loop 100 MHz ticks, rows, t_entry, t_loop_end, t_exit) per wave
+#endif
 struct S9A { f32x4 p0, p1; f32x2 p2; };
 __device__ __forceinline__ float s9_a(const S9A& a, int s) { return s < 4 ? a.p0[s] : (s < 8 ? a.p1[s - 4] : a.p2[s - 8]); }
 
@@ -308,6 +311,9 @@ __global__ __launch_bounds__(64 * S9_WAVES) void conv1_wgrad_ring_kernel(const X
     constexpr int PIECES = U8 ? 84 : 336, CH_PIECES = PIECES / 4, LAST = PIECES - 64 * (NP - 1);
     constexpr int SLOT = S9_QS * (int)sizeof(XT);                // bytes
     extern __shared__ __attribute__((aligned(16))) float s9_lds[];
+#ifdef S9_STAMP
+    const long long st_in = __builtin_amdgcn_s_memrealtime();
+#endif
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 31, h = lane >> 5;
     char* wl = reinterpret_cast<char*>(s9_lds + wave * S9_WAVE_FLOATS);
@@ -357,13 +363,26 @@ __global__ __launch_bounds__(64 * S9_WAVES) void conv1_wgrad_ring_kernel(const X
         a.p2 = *reinterpret_cast<const f32x2*>(p + 8);
         return a;
     };
+#ifdef S9_STAMP
+    const long long st_c0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (u0 < u1) {
         const int ul = u1 - 1;
         const int gs0 = (u0 / 20) * 21 + u0 % 20, gsl = (ul / 20) * 21 + ul % 20 + 1;
+        // the first two quads and the first dY row are requested together (one memory latency, not two, before the
+        // first MFMA; the second quad borrows registers the accumulators do not need yet)
         issue_quad(gs0);
-        write_quad(gs0);
+        u32x4 st0[NP];
+#pragma unroll
+        for (int i = 0; i < NP; ++i) st0[i] = st[i];
         issue_quad(gs0 + 1);                                    // (gs0 + 1 <= gsl: the range holds at least one row)
         S9A nxt = load_a(gs0 + 1);
+        {
+            char* dst = wl + (gs0 % 3) * SLOT + 16 * lane;
+#pragma unroll
+            for (int i = 0; i < NP - 1; ++i) *reinterpret_cast<u32x4*>(dst + 1024 * i) = st0[i];
+            if (lane < LAST) *reinterpret_cast<u32x4*>(dst + 1024 * (NP - 1)) = st0[NP - 1];
+        }
         for (int gs = gs0 + 1; gs <= gsl; ++gs) {
             const int k = gs % 21;
             const S9A cur = nxt;
@@ -409,6 +428,16 @@ __global__ __launch_bounds__(64 * S9_WAVES) void conv1_wgrad_ring_kernel(const X
             }
         }
     }
+#ifdef S9_STAMP
+    if (lane == 0) {
+        const int w = blockIdx.x * S9_WAVES + wave;
+        s9_stamps[6 * w] = __builtin_amdgcn_s_memtime() - st_c0;
+        s9_stamps[6 * w + 1] = __builtin_amdgcn_s_memrealtime() - st_r0;
+        s9_stamps[6 * w + 2] = u1 - u0;
+        s9_stamps[6 * w + 3] = st_in;
+        s9_stamps[6 * w + 4] = __builtin_amdgcn_s_memrealtime();
+    }
+#endif
     // fixed-order sum of the eight waves' partials: ((w0+w4) + (w2+w6)) + ((w1+w5) + (w3+w7)), through the (dead) rings
     __syncthreads();
     auto dump = [&](int slot) {
@@ -459,6 +488,9 @@ __global__ __launch_bounds__(64 * S9_WAVES) void conv1_wgrad_ring_kernel(const X
         for (int w = 1; w < S9_WAVES; ++w) t += bs[w * 32 + lane];
         slab[S1_OC * S1_KC + lane] = t;
     }
+#ifdef S9_STAMP
+    if (lane == 0) s9_stamps[6 * (blockIdx.x * S9_WAVES + wave) + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------------------------

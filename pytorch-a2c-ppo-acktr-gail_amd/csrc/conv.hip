@@ -607,8 +607,19 @@ extern "C" int acktr_conv2d_dgrad_carry_f32(const float* dy, const float* w, con
             ACKTR_ARG(!dx_padded, "conv2d_dgrad: dx_padded is only produced by the 3x3 stride-1 stationary path");
             if (!prepacked) rc = launch_sw_pack<SwD2>(w, img, 4 * C, 1, C, 2, s);
             if (rc) return rc;
+            // row classes (conv_sw.hpp): edge rows of the phase grid skip the kernel row that only reads padding.
+            // ACKTR_D2_ROWCLS=0 (tuning / comparison switch): every tile runs the full reduction
+            static const bool rowcls = [] { const char* v = getenv("ACKTR_D2_ROWCLS"); return !(v && v[0] == '0'); }();
             if (x_act) {
+                if (rowcls) {
+                    SwPhase2Epi<10, 10, 20, 20, true, true> epi{dx, x_act};
+                    return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s, carry);
+                }
                 SwPhase2Epi<10, 10, 20, 20, true> epi{dx, x_act};
+                return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s, carry);
+            }
+            if (rowcls) {
+                SwPhase2Epi<10, 10, 20, 20, false, true> epi{dx, nullptr};
                 return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s, carry);
             }
             SwPhase2Epi<10, 10, 20, 20, false> epi{dx, nullptr};

@@ -245,9 +245,13 @@ struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
 
 // stride-2 dgrad, CX == 32: M block = phase (py, px), one work item = the two px phases of row phase py = mg;
 // position r = (b, jy, jx) of the JH x JW phase grid; dX[b, cx, 2jy+py, 2jx + {0,1}] leaves as one 8-byte store
-template <int JH, int JW, int IH, int IW, bool GATED>
+// ROWCLS: the kernel deals the positions of the phase grid by ROW CLASS (see conv_sw_kernel): offset() below is unchanged,
+// r is still b*JP + jy*JW + jx.
+template <int JH, int JW, int IH, int IW, bool GATED, bool ROWCLS_ = false>
 struct SwPhase2Epi {
     float* dx; const float* xact;
+    static constexpr bool ROWCLS = ROWCLS_;
+    static constexpr int RC_JH = JH, RC_JW = JW;
     static constexpr int JP = JH * JW;
     __device__ __forceinline__ static long offset(int r, int mg) {
         const int b = r / JP, j = r % JP;
@@ -308,6 +312,32 @@ __device__ __forceinline__ float sw_tap(uint32_t v, int t) { return (float)((v >
 // kernel of its own: a dependent launch, a ramp, 19-34 MB of slabs) disappears from the step.
 struct SwCarry { acktr_slab_fin fin; int nvb; };      // nvb: virtual 256-thread blocks of slab_finalize_block
 
+// Row classes (stride-2 dgrad on the zero-padded dY, KH = 2): in the top row of the phase grid (jy = 0) the kernel row
+// ky = 0 reads nothing but the padding, in the bottom row (jy = JH - 1) the row ky = 1 does -- 10 % of the launch's MFMAs
+// multiply zeros there (and as many again in the first / last column, which stay).  With ROWCLS the tiles are built per
+// class: middle rows (full reduction), top rows (only the ky = 1 half of the chunk pairs: the same offsets one row further
+// down, the second half of the weight image), bottom rows (only the ky = 0 half).  The half items are numbered LAST, so
+// they also make the last rounds lighter: conv2 dgrad 74.1 -> 69.0 us inside the PPO step at 1024 rows.
+// Tried and dropped: (a) dealing the last full round wave-major as well, which evens the tail out to 6.0 item-times on the
+// busiest SIMD for 5.63 on average, lost more in L1 / L2 sharing than it gained (87.0 against 81.8 us stand-alone);
+// (b) column classes too (first / last column of the middle rows with one of a chunk's two taps): a tile of 32 positions
+// out of ONE column is 32 different rows of 4 images, every load and store of it touches 32 cache lines: 100 us;
+// (c) a mixed round (every workgroup's lower four waves a full item, its upper four a half item, so that all SIMDs end
+// within half an item of each other): 71.7 against 69.0 us -- runs of consecutive items per workgroup are worth more.
+template <class Epi, class = void>
+struct EpiRowCls : std::false_type {};
+template <class Epi>
+struct EpiRowCls<Epi, std::enable_if_t<Epi::ROWCLS>> : std::true_type {};
+template <class G, class Epi>
+__host__ __device__ inline int sw_num_tiles(int R) {
+    if constexpr (EpiRowCls<Epi>::value) {
+        const int B = R / (Epi::RC_JH * Epi::RC_JW);
+        return (B * (Epi::RC_JH - 2) * Epi::RC_JW + 31) / 32 + 2 * ((B * Epi::RC_JW + 31) / 32);
+    } else {
+        return (R + 31) / 32;
+    }
+}
+
 template <class G, class Epi, class XT = float>
 __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x,
                                                              const int64_t* __restrict__ idx,
@@ -348,14 +378,45 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
     constexpr long img_stride = (long)C * G::HW;
     const int half_off = h * G::HOFF;
 
-    auto lane_base = [&](int tile, int& r, bool& valid) -> const XT* {
-        r = tile * 32 + li;
-        valid = r < R;
+    constexpr bool RC = EpiRowCls<Epi>::value;
+    static_assert(!RC || (G::KH == 2 && G::NKXC == 1 && G::HM == HM_CH && NS % 2 == 0 && (G::J / 2) % 4 == 0),
+                  "row classes: two kernel rows, each one half of the chunk pairs");
+    int rc_mid = 0, rc_edge = 0, rc_B = 0;                   // tiles of the middle rows / of one edge row; images
+    if constexpr (RC) {
+        rc_B = R / (Epi::RC_JH * Epi::RC_JW);
+        rc_mid = (rc_B * (Epi::RC_JH - 2) * Epi::RC_JW + 31) / 32;
+        rc_edge = (rc_B * Epi::RC_JW + 31) / 32;
+    }
+    // tile -> the lane's position r, its window origin, and (row classes) which half of the reduction the item runs:
+    // nst stages starting at activation offset xoff / weight-image offset woff
+    auto lane_base = [&](int tile, int& r, bool& valid, int& nst, int& woff) -> const XT* {
+        int xoff = 0;
+        nst = NS; woff = 0;
+        if constexpr (RC) {
+            constexpr int JH = Epi::RC_JH, JW = Epi::RC_JW, MIDP = (JH - 2) * JW;
+            if (tile < rc_mid) {
+                const int e = tile * 32 + li;
+                valid = e < rc_B * MIDP;
+                const int ee = valid ? e : 0, b = ee / MIDP, q = ee % MIDP;
+                r = b * (JH * JW) + JW + q;
+            } else {
+                const bool top = tile < rc_mid + rc_edge;
+                const int e = (tile - rc_mid - (top ? 0 : rc_edge)) * 32 + li;
+                valid = e < rc_B * JW;
+                const int ee = valid ? e : 0, b = ee / JW, jx = ee % JW;
+                r = b * (JH * JW) + (top ? 0 : (JH - 1) * JW) + jx;
+                nst = NS / 2;
+                if (top) { xoff = G::W; woff = (G::J / 2) * TM * 64 * G::EP; }     // ky = 1: one row down, second half of the image
+            }
+        } else {
+            r = tile * 32 + li;
+            valid = r < R;
+        }
         const int rr = valid ? r : R - 1;
         const int b = rr / G::SP, sp = rr % G::SP;
         const int oy = sp / G::OW, ox = sp % G::OW;
         const long img = idx ? (long)idx[b] : (long)b;
-        return x + img * img_stride + (oy * G::S) * G::W + ox * G::S + half_off;
+        return x + img * img_stride + (oy * G::S) * G::W + ox * G::S + half_off + xoff;
     };
     auto stage_load = [&](VT (&buf)[NL], const XT* base, int s) {
 #pragma unroll
@@ -366,11 +427,10 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
     // itself the compiler issues each ds_read right in front of its consumer and exposes the LDS latency)
     constexpr int J = G::J;
     AT ring[4][TMW];
-    auto load_a = [&](int q, int mg) {       // q: chunk pair index (compile time after unrolling), may run past J
-        const float* la = lds_lane + mg * (TMW * 64 * G::EP);
+    auto load_a = [&](int q, const float* la) {       // q: chunk pair index within the item (compile time after unrolling)
 #pragma unroll
         for (int a = 0; a < TMW; ++a)
-            ring[q & 3][a] = *reinterpret_cast<const AT*>(la + ((q % J) * TM + a) * 64 * G::EP);
+            ring[q & 3][a] = *reinterpret_cast<const AT*>(la + (q * TM + a) * 64 * G::EP);
     };
 
     // work items (tile, M group) are dealt round-robin over all waves of the grid: every CU gets the same number of
@@ -395,11 +455,12 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
 
     VT buf[2][NL];
     int r; bool valid;
-    int mg = item % MG;
-    const XT* base = lane_base(item / MG, r, valid);
+    int mg = item % MG, nst, woff;
+    const XT* base = lane_base(item / MG, r, valid, nst, woff);
+    const float* la = lds_lane + mg * (TMW * 64 * G::EP) + woff;
     stage_load(buf[0], base, 0);
-    load_a(0, mg);
-    load_a(1, mg);
+    load_a(0, la);
+    load_a(1, la);
 
     while (true) {
         f32x16 acc[TMW];
@@ -413,37 +474,50 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
         int r_next = 0; bool valid_next = false;
         const XT* base_next = base;
         const int mg_next = has_next ? next_item % MG : mg;
-        if (has_next) base_next = lane_base(next_item / MG, r_next, valid_next);
+        int nst_next = nst, woff_next = woff;
+        if (has_next) base_next = lane_base(next_item / MG, r_next, valid_next, nst_next, woff_next);
+        const float* la_next = lds_lane + mg_next * (TMW * 64 * G::EP) + woff_next;
 
         typename Epi::template Pre<TMW> pre;
+        // one item: NST stages of NL chunk pairs (row classes: NS / 2 for the edge rows)
+        auto run = [&](auto nst_c) {
+            constexpr int NST = decltype(nst_c)::value, JN = NST * NL;
 #pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            if (s == NS - 1) {                 // the epilogue's own reads fly over the last stage of MFMAs
-                epi.template prefetch<TMW>(r, valid, h, mg, pre);
-                __builtin_amdgcn_sched_barrier(0);
+            for (int s = 0; s < NST; ++s) {
+                if (s == NST - 1) {                // the epilogue's own reads fly over the last stage of MFMAs
+                    epi.template prefetch<TMW>(r, valid, h, mg, pre);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // the activations of stage s+1 (or of the next item's stage 0: it flies over the epilogue) are requested
+                // a whole stage of MFMAs before they are needed
+                // (unconditional: behind a branch the compiler can no longer count the loads in flight and drains them;
+                //  the last item simply re-requests its own first stage)
+                if (s + 1 < NST) stage_load(buf[(s + 1) & 1], base, s + 1);
+                else stage_load(buf[0], base_next, 0);
+#pragma unroll
+                for (int i = 0; i < NL; ++i) {
+                    const int q = s * NL + i;
+                    if (q + 2 < JN) load_a(q + 2, la); else load_a(q + 2 - JN, la_next);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < G::E; ++t)
+#pragma unroll
+                        for (int a = 0; a < TMW; ++a)
+                            acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[q & 3][a][t], sw_tap(buf[s & 1][i], t), acc[a], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
-            // the activations of stage s+1 (or of the next item's stage 0: it flies over the epilogue) are requested
-            // a whole stage of MFMAs before they are needed
-            // (unconditional: behind a branch the compiler can no longer count the loads in flight and drains them;
-            //  the last item simply re-requests its own first stage)
-            if (s + 1 < NS) stage_load(buf[(s + 1) & 1], base, s + 1);
-            else stage_load(buf[0], base_next, 0);
-#pragma unroll
-            for (int i = 0; i < NL; ++i) {
-                const int q = s * NL + i;
-                load_a(q + 2, q + 2 < J ? mg : mg_next);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int t = 0; t < G::E; ++t)
-#pragma unroll
-                    for (int a = 0; a < TMW; ++a)
-                        acc[a] = __builtin_amdgcn_mfma_f32_32x32x2f32(ring[q & 3][a][t], sw_tap(buf[s & 1][i], t), acc[a], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+        };
+        if constexpr (RC) {
+            if (nst == NS) run(std::integral_constant<int, NS>{});
+            else run(std::integral_constant<int, NS / 2>{});
+        } else {
+            run(std::integral_constant<int, NS>{});
         }
         epi.template store<TMW>(r, valid, h, mg, acc, pre);
         if (!has_next) break;
-        item = next_item; base = base_next; r = r_next; valid = valid_next; mg = mg_next; ++kround;
+        item = next_item; base = base_next; r = r_next; valid = valid_next; mg = mg_next; nst = nst_next; woff = woff_next;
+        la = la_next; ++kround;
     }
 }
 
@@ -453,7 +527,7 @@ template <class G, class Epi, class XT = float>
 int launch_conv_sw(const XT* x, const int64_t* idx, const float* wimg, const Epi& epi, int R, hipStream_t stream,
                    const acktr_slab_fin* carry = nullptr) {
     static_assert(G::NT % 256 == 0, "carry workgroups run virtual 256-thread blocks");
-    const int ntiles = cdiv(R, 32);
+    const int ntiles = sw_num_tiles<G, Epi>(R);
     constexpr int smem_bytes = (int)G::lds_bytes();
     auto kern = conv_sw_kernel<G, Epi, XT>;
     if (smem_bytes > 48 * 1024) {

@@ -58,6 +58,7 @@ def main():
         'conv3s1_dgrad': (lambda: ops.conv2d_dgrad(dy3, w3, a2, 1, out=dx3), 2.0 * a3.numel() * 64 * 9),
         'conv3s1_wgrad': (lambda: ops.conv2d_wgrad(a2, dy3, w3.shape, 1, dw3, db3), 2.0 * a3.numel() * 64 * 9),
         'conv4s2_dgrad': (lambda: ops.conv2d_dgrad(dy2, w2, a1, 2, out=dx2), 2.0 * a2.numel() * 32 * 16),
+        'conv4s2_dgrad_nogate': (lambda: ops.conv2d_dgrad(dy2, w2, None, 2, out=dx2), 2.0 * a2.numel() * 32 * 16),
         'conv4s2_wgrad': (lambda: ops.conv2d_wgrad(a1, dy2, w2.shape, 2, dw2, db2), 2.0 * a2.numel() * 32 * 16),
         'conv8s4_wgrad': (lambda: ops.conv2d_wgrad(x0, dy1, w1.shape, 4, dw1, db1, in_scale=1 / 255.0), 2.0 * a1.numel() * 4 * 64),
     }

@@ -136,6 +136,17 @@ int acktr_conv2d_dgrad_ex_f32(const float* dy, const float* w, const float* x_ac
 int acktr_conv2d_dgrad_carry_f32(const float* dy, const float* w, const float* x_act, float* dx, int B, int C, int H,
                                  int W, int OC, int KH, int KW, int S, void* workspace, long workspace_bytes, int flags,
                                  float* dx_padded, int pad, const acktr_slab_fin* carry, void* stream);
+/* The ReLU gate as BITS (data layout only; no counterpart in the reference, whose autograd keeps the whole activation
+ * for ReLU's backward, model.py:177).  The forward of the 8x8 stride-4 layer on its stationary-weight path (workspace
+ * given) also writes gate_mask: word [r / 32][oc] (uint32, OC words per 32 positions, r = b*OH*OW + oy*OW + ox) holds
+ * bit (r % 32) = (y[b, oc, oy, ox] > 0); acktr_conv2d_gate_mask_bytes(B, OC, OH, OW) bytes, 16-byte aligned.  The input
+ * gradient of the FOLLOWING 4x4 stride-2 layer (32 input channels, 20x20) reads it in place of x_act when flags bit 2 of
+ * acktr_conv2d_dgrad_ex_f32 / _carry_f32 is set (x_act then points at the mask): 1.6 MB instead of 52 MB at 1024
+ * frames.  Results are bit-identical to the float gate.  Other shapes reject the mask. */
+long acktr_conv2d_gate_mask_bytes(int B, int OC, int OH, int OW);
+int acktr_conv2d_fwd_gate_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
+                              int B, int C, int H, int W, int OC, int KH, int KW, int S, float in_scale, int relu,
+                              void* workspace, long workspace_bytes, int prepacked, uint32_t* gate_mask, void* stream);
 
 
 /* Re-ordered weights of up to 8 conv layers in ONE launch (no counterpart call in the reference: it is the weight
@@ -281,6 +292,10 @@ int acktr_dist_bwd_f32(int dist, const float* dist_in, long ld, const float* log
  * acktr_kfac_cov_workspace_bytes(256, B * 400). */
 int acktr_conv1_fwd_u8(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y, int B,
                        float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked, void* stream);
+/* (with the gate bits of acktr_conv2d_fwd_gate_f32) */
+int acktr_conv1_fwd_u8_gate(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
+                            int B, float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                            uint32_t* gate_mask, void* stream);
 long acktr_conv1_wgrad_u8_workspace_bytes(int B);
 int acktr_conv1_wgrad_u8(const uint8_t* x, const int64_t* gather_idx, const float* dy, float* dw, float* db, int B,
                          float in_scale, void* workspace, long workspace_bytes, acktr_slab_fin* pending, void* stream);

@@ -100,9 +100,12 @@ _PROTOS = {
     'acktr_gather_rows': (c_i, [c_p, c_p, c_p, c_l, c_l, c_l, c_p]),
     'acktr_conv2d_fwd_workspace_bytes': (c_l, [c_i] * 7),
     'acktr_conv2d_fwd_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_i, c_p, c_l, c_i, c_p]),
+    'acktr_conv2d_gate_mask_bytes': (c_l, [c_i] * 4),
+    'acktr_conv2d_fwd_gate_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_i, c_p, c_l, c_i, c_p, c_p]),
     'acktr_conv2d_wgrad_workspace_bytes': (c_l, [c_i] * 8),
     'acktr_conv2d_wgrad_f32': (c_i, [c_p, c_p, c_p, c_p, c_p] + [c_i] * 8 + [c_f, c_p, c_l, c_p]),
     'acktr_conv1_fwd_u8': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_l, c_i, c_p]),
+    'acktr_conv1_fwd_u8_gate': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_i, c_p, c_l, c_i, c_p, c_p]),
     'acktr_conv1_wgrad_u8_workspace_bytes': (c_l, [c_i]),
     'acktr_conv1_wgrad_u8': (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_l, ctypes.POINTER(SlabFin), c_p]),
     'acktr_kfac_cov_a_conv1_u8': (c_i, [c_p, c_p, c_i, c_f, c_p, c_p, c_l, c_p]),

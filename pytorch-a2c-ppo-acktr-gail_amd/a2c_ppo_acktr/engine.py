@@ -286,8 +286,12 @@ def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True
         pk = ops.pack_conv_weights(_conv_image_layers(L), B, policy.__dict__.setdefault('_pack_ws', {}),
                                    trust=trust_images and TRUST_IMAGES)
         a.packs = pk
+        # conv2's input gradient needs only the sign of y1: the conv1 forward leaves it as bits (1.6 MB instead of a second
+        # pass over 52 MB at 1024 frames) when both layers run their stationary-weight kernels
+        a.g1 = ops.gate_mask_like(B, 32, 20, 20, inputs.device) \
+            if (GATE_BITS and pk.get('f1') is not None and pk.get('d2') is not None) else None
         a.y1 = ops.conv2d_fwd(inputs, L['conv1'][0], L['conv1'][1].view(-1), 4, in_scale=1.0 / 255.0, relu=True,
-                              gather_idx=gather_idx, packed=pk.get('f1'))
+                              gather_idx=gather_idx, packed=pk.get('f1'), gate_mask=a.g1)
         a.y2 = ops.conv2d_fwd(a.y1, L['conv2'][0], L['conv2'][1].view(-1), 2, packed=pk.get('f2'))
         a.y3 = ops.conv2d_fwd(a.y2, L['conv3'][0], L['conv3'][1].view(-1), 1, packed=pk.get('f3'))
         a.flat3 = a.y3.view(a.y3.shape[0], -1)
@@ -415,7 +419,7 @@ def backward(policy, acts, gflat, keep=False, wgrad=True, phase=None, defer_last
         if wgrad:
             ops.conv2d_wgrad(acts.y1, dy2, tuple(w2.shape), 2, gv(w2), gv(L['conv2'][1]).view(-1), pending=carry2)
         dy1 = ops.conv2d_dgrad(dy2, w2, acts.y1, 2, packed=acts.packs.get('d2'), dy_prepadded=pd2 is not None,
-                               carry=carry2)
+                               carry=carry2, gate_bits=getattr(acts, 'g1', None))
         if wgrad:
             ops.conv2d_wgrad(acts.obs, dy1, tuple(w1.shape), 4, gv(w1), gv(L['conv1'][1]).view(-1),
                              in_scale=1.0 / 255.0, gather_idx=acts.idx, pending=defer_last)
@@ -493,6 +497,7 @@ def policy_loss(policy, acts, algo, actions, loss_acc, inv_batch, old_logp=None,
 FUSED_HEAD = os.environ.get('ACKTR_FUSED_HEAD', '1') != '0'
 FOLD_FC_SLABS = os.environ.get('ACKTR_FOLD_FC_SLABS', '1') != '0'      # comparison switch
 CARRY_SLABS = os.environ.get('ACKTR_CARRY_SLABS', '1') != '0'          # comparison switch
+GATE_BITS = os.environ.get('ACKTR_GATE_BITS', '1') != '0'              # comparison switch (conv1's ReLU gate as bits)
 TRUST_IMAGES = os.environ.get('ACKTR_ADAM_PACKS', '1') != '0'          # comparison switch (optimiser keeps the weight images)
 
 

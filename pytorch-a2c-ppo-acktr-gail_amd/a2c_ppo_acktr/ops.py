@@ -219,8 +219,16 @@ def conv_image_map(layers, B, cache, offset_of):
     return pm
 
 
-def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out=None, packed=None):
-    """y = relu?(in_scale*conv2d(x[gather_idx], w) + bias); x [Bsrc,C,H,W], w [OC,C,KH,KW]."""
+def gate_mask_like(B, OC, OH, OW, device):
+    """Buffer for the ReLU gate of a [B,OC,OH,OW] conv output as bits (acktr_conv2d_gate_mask_bytes)."""
+    nb = _hip.lib().acktr_conv2d_gate_mask_bytes(B, OC, OH, OW)
+    return torch.empty(nb // 4, dtype=torch.int32, device=device)
+
+
+def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out=None, packed=None, gate_mask=None):
+    """y = relu?(in_scale*conv2d(x[gather_idx], w) + bias); x [Bsrc,C,H,W], w [OC,C,KH,KW].
+    gate_mask (int32 words, gate_mask_like): also receives (y > 0) as bits for conv2d_dgrad(gate_bits=) of the next
+    layer -- the 8x8 stride-4 layer on its stationary path only."""
     OC, C, KH, KW = w.shape
     H, W = x.shape[-2], x.shape[-1]
     assert x.shape[-3] == C, 'channel mismatch'
@@ -236,18 +244,25 @@ def conv2d_fwd(x, w, bias, stride, in_scale=1.0, relu=True, gather_idx=None, out
         if (C, H, W, OC, KH, KW, stride) != (4, 84, 84, 32, 8, 8, 4) or ws is None:
             raise RuntimeError('uint8 inputs are supported for the first NatureCNN layer only (4x84x84, 32 filters 8x8 s4)')
         with _Timed('conv%ds%d_fwd' % (KH, stride), 2.0 * B * OH * OW * OC * C * KH * KW):
-            rc = L.acktr_conv1_fwd_u8(_p(x, 'x', torch.uint8), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'),
-                                      _p(bias, 'bias'), _p(out, 'y'), B, float(in_scale), 1 if relu else 0,
-                                      _p(ws, 'workspace', torch.uint8), ws.numel(), 1 if packed is not None else 0,
-                                      _hip.cur_stream(x.device))
+            args = (_p(x, 'x', torch.uint8), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'),
+                    _p(bias, 'bias'), _p(out, 'y'), B, float(in_scale), 1 if relu else 0,
+                    _p(ws, 'workspace', torch.uint8), ws.numel(), 1 if packed is not None else 0)
+            if gate_mask is not None:
+                assert gate_mask.numel() * 4 >= L.acktr_conv2d_gate_mask_bytes(B, OC, OH, OW)
+                rc = L.acktr_conv1_fwd_u8_gate(*args, _p(gate_mask, 'gate_mask', torch.int32), _hip.cur_stream(x.device))
+            else:
+                rc = L.acktr_conv1_fwd_u8(*args, _hip.cur_stream(x.device))
         _hip.check(rc, 'acktr_conv1_fwd_u8')
         return out
     with _Timed('conv%ds%d_fwd' % (KH, stride), 2.0 * B * OH * OW * OC * C * KH * KW):
-        rc = L.acktr_conv2d_fwd_f32(
-            _p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
-            B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0,
-            _p(ws, 'workspace', torch.uint8), ws.numel() if ws is not None else 0, 1 if packed is not None else 0,
-            _hip.cur_stream(x.device))
+        args = (_p(x, 'x'), _p(gather_idx, 'gather_idx', torch.int64), _p(w, 'w'), _p(bias, 'bias'), _p(out, 'y'),
+                B, C, H, W, OC, KH, KW, stride, float(in_scale), 1 if relu else 0,
+                _p(ws, 'workspace', torch.uint8), ws.numel() if ws is not None else 0, 1 if packed is not None else 0)
+        if gate_mask is not None:
+            assert gate_mask.numel() * 4 >= L.acktr_conv2d_gate_mask_bytes(B, OC, OH, OW)
+            rc = L.acktr_conv2d_fwd_gate_f32(*args, _p(gate_mask, 'gate_mask', torch.int32), _hip.cur_stream(x.device))
+        else:
+            rc = L.acktr_conv2d_fwd_f32(*args, _hip.cur_stream(x.device))
     _hip.check(rc, 'acktr_conv2d_fwd_f32')
     return out
 
@@ -307,11 +322,13 @@ def padded_dy_view(packed, B, w, stride, in_hw):
     return packed[off:off + 4 * n].view(f32).view(B, OC, 11, 11)
 
 
-def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None, dy_prepadded=False, padded_out=None, carry=None):
+def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None, dy_prepadded=False, padded_out=None, carry=None,
+                 gate_bits=None):
     """dx = conv_transpose(dy, w) * (x_act > 0); x_act [B,C,H,W] is the (post-ReLU) input of the layer.
     dy_prepadded: `packed` already holds this dY zero-padded (see padded_dy_view); padded_out [B,C,H+2p,W+2p]: dx is
     also written there, interior only.  carry (a _hip.SlabFin left pending by conv2d_wgrad(pending=...)): that weight
-    gradient's slab sum rides in this launch (acktr_conv2d_dgrad_carry_f32)."""
+    gradient's slab sum rides in this launch (acktr_conv2d_dgrad_carry_f32).
+    gate_bits (int32 words written by conv2d_fwd(gate_mask=) of the layer that produced x_act): read instead of x_act."""
     OC, C, KH, KW = w.shape
     B, _, OH, OW = dy.shape
     H, W = (OH - 1) * stride + KH, (OW - 1) * stride + KW
@@ -327,9 +344,14 @@ def conv2d_dgrad(dy, w, x_act, stride, out=None, packed=None, dy_prepadded=False
     ws = packed if packed is not None else \
         workspace(dy.device, L.acktr_conv2d_dgrad_workspace_bytes(B, C, H, W, OC, KH, KW, stride), tag='dgrad')
     with _Timed('conv%ds%d_dgrad' % (KH, stride), 2.0 * dy.numel() * C * KH * KW):
-        rc = L.acktr_conv2d_dgrad_carry_f32(_p(dy, 'dy'), _p(w, 'w'), _p(x_act, 'x_act'), _p(out, 'dx'),
+        gate = _p(x_act, 'x_act')
+        if gate_bits is not None:
+            assert gate_bits.numel() * 4 >= L.acktr_conv2d_gate_mask_bytes(B, C, H, W)
+            gate = _p(gate_bits, 'gate_bits', torch.int32)
+        rc = L.acktr_conv2d_dgrad_carry_f32(_p(dy, 'dy'), _p(w, 'w'), gate, _p(out, 'dx'),
                                             B, C, H, W, OC, KH, KW, stride, _p(ws, 'workspace', torch.uint8), ws.numel(),
-                                            (1 if packed is not None else 0) | (2 if dy_prepadded else 0),
+                                            (1 if packed is not None else 0) | (2 if dy_prepadded else 0)
+                                            | (4 if gate_bits is not None else 0),
                                             _p(padded_out, 'dx_padded'), pad,
                                             ctypes.byref(carry) if (carry is not None and carry.dst) else None,
                                             _hip.cur_stream(dy.device))

@@ -361,10 +361,10 @@ extern "C" long acktr_conv2d_fwd_workspace_bytes(int C, int H, int W, int OC, in
     return sw_fwd_image_bytes(geom, C, OC);
 }
 
-extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias,
-                                    float* y, int B, int C, int H, int W, int OC, int KH, int KW, int S,
-                                    float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
-                                    void* stream) {
+static int conv2d_fwd_impl(const float* x, const int64_t* gather_idx, const float* w, const float* bias,
+                           float* y, int B, int C, int H, int W, int OC, int KH, int KW, int S,
+                           float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                           unsigned* gate_mask, void* stream) {
     ACKTR_ARG(x && w && y, "conv2d_fwd: null pointer");
     const bool gather_ok = true;
     CONV_COMMON_CHECKS("conv2d_fwd");
@@ -380,12 +380,13 @@ extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, c
             if (!prepacked) rc = launch_sw_pack<SwF1>(w, img, OC, 0, 0, 0, s);
             if (rc) return rc;
             if (bias) {
-                SwFwdEpi<SwF1::SP, true> epi{y, bias, OC, in_scale, relu};
+                SwFwdEpi<SwF1::SP, true> epi{y, bias, OC, in_scale, relu, gate_mask};
                 return launch_conv_sw<SwF1>(x, gather_idx, img, epi, B * SwF1::SP, s);
             }
-            SwFwdEpi<SwF1::SP, false> epi{y, nullptr, OC, in_scale, relu};
+            SwFwdEpi<SwF1::SP, false> epi{y, nullptr, OC, in_scale, relu, gate_mask};
             return launch_conv_sw<SwF1>(x, gather_idx, img, epi, B * SwF1::SP, s);
         }
+        ACKTR_ARG(!gate_mask, "conv2d_fwd_gate: the gate mask is written by the 8x8 stride-4 stationary-weight path only");
         if (geom == GEOM_4S2) {
             if (!prepacked) rc = launch_sw_pack<SwF2>(w, img, OC, 0, 0, 0, s);
             if (rc) return rc;
@@ -405,6 +406,8 @@ extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, c
         SwFwdEpi<SwF3::SP, false> epi{y, nullptr, OC, in_scale, relu};
         return launch_conv_sw<SwF3>(x, gather_idx, img, epi, B * SwF3::SP, s);
     }
+    ACKTR_ARG(!gate_mask, "conv2d_fwd_gate: the gate mask is written by the 8x8 stride-4 stationary-weight path only "
+                          "(needs the weight-image workspace)");
     if (geom == GEOM_8S4) {
         if (OC <= 32) return conv_fwd_t<8, 8, 4, 84, 84, 32, 1, 4>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
         return conv_fwd_t<8, 8, 4, 84, 84, 64, 2, 2>(x, gather_idx, w, bias, y, B, C, OC, in_scale, relu, s);
@@ -419,6 +422,26 @@ extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, c
     }
     if (OC <= 32) return conv_fwd_pos_t<3, 3, 9, 9, 8, 32, 1, 4>(x, w, bias, y, B, C, OC, in_scale, relu, s);
     return conv_fwd_pos_t<3, 3, 9, 9, 8, 64, 2, 2>(x, w, bias, y, B, C, OC, in_scale, relu, s);
+}
+
+extern "C" int acktr_conv2d_fwd_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias,
+                                    float* y, int B, int C, int H, int W, int OC, int KH, int KW, int S,
+                                    float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                                    void* stream) {
+    return conv2d_fwd_impl(x, gather_idx, w, bias, y, B, C, H, W, OC, KH, KW, S, in_scale, relu, workspace, workspace_bytes,
+                           prepacked, nullptr, stream);
+}
+extern "C" long acktr_conv2d_gate_mask_bytes(int B, int OC, int OH, int OW) {
+    if (B <= 0 || OC <= 0 || OH <= 0 || OW <= 0) return 0;
+    return (((long)B * OH * OW + 31) / 32) * OC * (long)sizeof(unsigned);
+}
+extern "C" int acktr_conv2d_fwd_gate_f32(const float* x, const int64_t* gather_idx, const float* w, const float* bias,
+                                         float* y, int B, int C, int H, int W, int OC, int KH, int KW, int S,
+                                         float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                                         uint32_t* gate_mask, void* stream) {
+    ACKTR_ARG(gate_mask && ((uintptr_t)gate_mask & 15) == 0, "conv2d_fwd_gate: gate_mask must be given, 16-byte aligned");
+    return conv2d_fwd_impl(x, gather_idx, w, bias, y, B, C, H, W, OC, KH, KW, S, in_scale, relu, workspace, workspace_bytes,
+                           prepacked, gate_mask, stream);
 }
 
 extern "C" long acktr_conv2d_wgrad_workspace_bytes(int B, int C, int H, int W, int OC, int KH, int KW, int S) {
@@ -485,9 +508,9 @@ extern "C" long acktr_conv1_wgrad_u8_workspace_bytes(int B) {
     return (long)(sa1_wgrad_slabs(B) + SLAB_GROUP_EXTRA) * ((long)S1_OC * S1_KC + S1_OC) * (long)sizeof(float);
 }
 
-extern "C" int acktr_conv1_fwd_u8(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
-                                  int B, float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
-                                  void* stream) {
+static int conv1_fwd_u8_impl(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
+                             int B, float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                             unsigned* gate_mask, void* stream) {
     ACKTR_ARG(x && w && y && workspace, "conv1_fwd_u8: null pointer");
     ACKTR_ARG(B > 0 && (long)B * 32 * 400 < (1L << 31), "conv1_fwd_u8: bad batch size %d", B);
     ACKTR_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
@@ -497,11 +520,22 @@ extern "C" int acktr_conv1_fwd_u8(const uint8_t* x, const int64_t* gather_idx, c
     float* img = (float*)workspace;
     if (!prepacked) { const int rc = launch_sw_pack<SwF1>(w, img, 32, 0, 0, 0, s); if (rc) return rc; }
     if (bias) {
-        SwFwdEpi<SwF1::SP, true> epi{y, bias, 32, in_scale, relu};
+        SwFwdEpi<SwF1::SP, true> epi{y, bias, 32, in_scale, relu, gate_mask};
         return launch_conv_sw<SwF1, SwFwdEpi<SwF1::SP, true>, uint8_t>(x, gather_idx, img, epi, B * SwF1::SP, s);
     }
-    SwFwdEpi<SwF1::SP, false> epi{y, nullptr, 32, in_scale, relu};
+    SwFwdEpi<SwF1::SP, false> epi{y, nullptr, 32, in_scale, relu, gate_mask};
     return launch_conv_sw<SwF1, SwFwdEpi<SwF1::SP, false>, uint8_t>(x, gather_idx, img, epi, B * SwF1::SP, s);
+}
+extern "C" int acktr_conv1_fwd_u8(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
+                                  int B, float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                                  void* stream) {
+    return conv1_fwd_u8_impl(x, gather_idx, w, bias, y, B, in_scale, relu, workspace, workspace_bytes, prepacked, nullptr, stream);
+}
+extern "C" int acktr_conv1_fwd_u8_gate(const uint8_t* x, const int64_t* gather_idx, const float* w, const float* bias, float* y,
+                                       int B, float in_scale, int relu, void* workspace, long workspace_bytes, int prepacked,
+                                       uint32_t* gate_mask, void* stream) {
+    ACKTR_ARG(gate_mask && ((uintptr_t)gate_mask & 15) == 0, "conv1_fwd_u8_gate: gate_mask must be given, 16-byte aligned");
+    return conv1_fwd_u8_impl(x, gather_idx, w, bias, y, B, in_scale, relu, workspace, workspace_bytes, prepacked, gate_mask, stream);
 }
 
 extern "C" int acktr_conv1_wgrad_u8(const uint8_t* x, const int64_t* gather_idx, const float* dy, float* dw, float* db,
@@ -571,13 +605,17 @@ extern "C" int acktr_conv2d_dgrad_carry_f32(const float* dy, const float* w, con
                                             const acktr_slab_fin* carry, void* stream) {
     const int prepacked = flags & 1;
     const bool prepadded = (flags & 2) != 0;      // the zero-padded dY already sits in the workspace (a producer wrote it)
+    const bool gate_bits = (flags & 4) != 0;      // x_act holds the gate as bits (acktr_conv2d_fwd_gate_f32's gate_mask)
     ACKTR_ARG((dy || prepadded) && w && dx, "conv2d_dgrad: null pointer");
+    ACKTR_ARG(!gate_bits || (x_act && ((uintptr_t)x_act & 15) == 0), "conv2d_dgrad: flags bit 2 needs a 16-byte aligned gate mask in x_act");
     ACKTR_ARG(!dx_padded || (pad > 0 && pad <= 4), "conv2d_dgrad: dx_padded needs 1 <= pad <= 4");
     const bool gather_ok = false;
     CONV_COMMON_CHECKS("conv2d_dgrad");
     ACKTR_ARG(workspace && workspace_bytes >= dgrad_ws_floats(B, C, H, W, OC, KH, KW, S) * (long)sizeof(float),
               "conv2d_dgrad: workspace too small (%ld bytes given)", workspace_bytes);
     ACKTR_ARG(((uintptr_t)workspace & 15) == 0, "conv2d_dgrad: workspace must be 16-byte aligned");
+    ACKTR_ARG(!gate_bits || (geom == GEOM_4S2 && sw_dgrad_ok(geom, C, OC) && (long)B * OC * 121 < (1L << 31)),
+              "conv2d_dgrad: a gate mask (flags bit 2) is read by the 4x4 stride-2 stationary-weight path only");
     hipStream_t s = (hipStream_t)stream;
     float* wp = (float*)workspace;
     if (d3_oa(geom, C, OC) && sw_dgrad_ok(geom, C, OC) && (long)B * C * 121 < (1L << 31)) {
@@ -610,6 +648,14 @@ extern "C" int acktr_conv2d_dgrad_carry_f32(const float* dy, const float* w, con
             // row classes (conv_sw.hpp): edge rows of the phase grid skip the kernel row that only reads padding.
             // ACKTR_D2_ROWCLS=0 (tuning / comparison switch): every tile runs the full reduction
             static const bool rowcls = [] { const char* v = getenv("ACKTR_D2_ROWCLS"); return !(v && v[0] == '0'); }();
+            if (gate_bits) {
+                if (rowcls) {
+                    SwPhase2Epi<10, 10, 20, 20, 2, true> epi{dx, x_act};
+                    return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s, carry);
+                }
+                SwPhase2Epi<10, 10, 20, 20, 2> epi{dx, x_act};
+                return launch_conv_sw<SwD2>(dyp, nullptr, img, epi, B * 100, s, carry);
+            }
             if (x_act) {
                 if (rowcls) {
                     SwPhase2Epi<10, 10, 20, 20, true, true> epi{dx, x_act};

@@ -160,6 +160,9 @@ __global__ __launch_bounds__(256) void sw_pad_kernel(const float* __restrict__ d
 template <int SP, bool BIASED>
 struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
     float* y; const float* bias; int M; float scale; int relu;
+    // optional: the ReLU gate of Y as bits -- word [r / 32][m] holds (Y > 0) of the 32 positions r of a tile (r = b*SP + sp),
+    // which is all the layer's input gradient needs of Y (52 MB as floats, 1.6 MB as bits for conv1 at 1024 frames)
+    unsigned* gmask = nullptr;
     template <int TM> struct Pre { float bv[BIASED ? TM : 1][16]; };
     template <int TM>
     __device__ __forceinline__ void prefetch(int, bool, int h, int mg, Pre<TM>& p) const {   // (see SwGateEpi)
@@ -189,6 +192,23 @@ struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
                 if constexpr (BIASED) v += p.bv[a][g];
                 if (relu) v = v > 0.f ? v : 0.f;
                 if (valid && (full || m < M)) y[off + (long)m * SP] = v;
+            }
+        }
+        if (gmask) {        // (wave-uniform; every lane of the wave is here: r = 32*tile + li, so r >> 5 is the tile)
+            const int li = threadIdx.x & 31;
+#pragma unroll
+            for (int a = 0; a < TM; ++a) {
+                unsigned word = 0;                             // lane li < 16 ends up with the word of ITS row g = li
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    float v = acc[a][g] * scale;
+                    if constexpr (BIASED) v += p.bv[a][g];
+                    const unsigned long long bal = __ballot(valid && v > 0.f);
+                    const unsigned mine = h ? (unsigned)(bal >> 32) : (unsigned)bal;
+                    word = li == g ? mine : word;
+                }
+                const int m = m0 + 32 * a + (li & 3) + 8 * (li >> 2) + 4 * h;
+                if (li < 16 && (full || m < M)) gmask[(long)(r >> 5) * M + m] = word;      // 32 words of one 128-byte line
             }
         }
     }
@@ -247,7 +267,10 @@ struct SwGateEpi {      // stride-1 dgrad: dX[b, m, sp] = acc * (xact > 0)
 // position r = (b, jy, jx) of the JH x JW phase grid; dX[b, cx, 2jy+py, 2jx + {0,1}] leaves as one 8-byte store
 // ROWCLS: the kernel deals the positions of the phase grid by ROW CLASS (see conv_sw_kernel): offset() below is unchanged,
 // r is still b*JP + jy*JW + jx.
-template <int JH, int JW, int IH, int IW, bool GATED, bool ROWCLS_ = false>
+// GATED: 0 = no gate, 1 = xact holds the layer's input (floats, gate = x > 0), 2 = xact holds the gate as bits in the layout
+// SwFwdEpi::gmask writes (word [R1 / 32][cx], R1 = b*IH*IW + pixel): the 16 channel words of a lane are four 16-byte loads
+// out of ONE 128-byte line instead of sixteen 8-byte loads out of sixteen planes.
+template <int JH, int JW, int IH, int IW, int GATED, bool ROWCLS_ = false>
 struct SwPhase2Epi {
     float* dx; const float* xact;
     static constexpr bool ROWCLS = ROWCLS_;
@@ -258,10 +281,21 @@ struct SwPhase2Epi {
         const int jy = j / JW, jx = j % JW;
         return (long)b * 32 * (IH * IW) + (2 * jy + mg) * IW + 2 * jx;
     }
-    template <int TM> struct Pre { f32x2 gt[GATED ? 16 : 1]; };
+    typedef unsigned int gw4 __attribute__((ext_vector_type(4)));
+    template <int TM> struct Pre { f32x2 gt[GATED == 1 ? 16 : 1]; gw4 gw[GATED == 2 ? 4 : 1]; };
+    __device__ __forceinline__ static int pixel_index(int r, int mg) {      // R1 of the lane's left pixel (even)
+        const int b = r / JP, j = r % JP;
+        return b * (IH * IW) + (2 * (j / JW) + mg) * IW + 2 * (j % JW);
+    }
     template <int TM>
     __device__ __forceinline__ void prefetch(int r, bool valid, int h, int mg, Pre<TM>& p) const {
-        if constexpr (GATED) {
+        if constexpr (GATED == 2) {
+            const int R1 = pixel_index(valid ? r : 0, mg);
+            const gw4* gm = reinterpret_cast<const gw4*>(reinterpret_cast<const unsigned*>(xact) + (long)(R1 >> 5) * 32 + 4 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) p.gw[q] = gm[2 * q];          // channels 8q + 4h .. + 3
+        }
+        if constexpr (GATED == 1) {
             const long off = offset(valid ? r : 0, mg);
 #pragma unroll
             for (int g = 0; g < 16; ++g) {
@@ -282,9 +316,14 @@ struct SwPhase2Epi {
             f32x2 v;
             v[0] = acc[0][g];
             v[1] = acc[1][g];
-            if constexpr (GATED) {
+            if constexpr (GATED == 1) {
                 v[0] = p.gt[g][0] > 0.f ? v[0] : 0.f;
                 v[1] = p.gt[g][1] > 0.f ? v[1] : 0.f;
+            }
+            if constexpr (GATED == 2) {
+                const unsigned wbits = p.gw[g >> 2][g & 3] >> (pixel_index(r, mg) & 31);
+                v[0] = (wbits & 1u) ? v[0] : 0.f;
+                v[1] = (wbits & 2u) ? v[1] : 0.f;
             }
             *reinterpret_cast<f32x2*>(dx + off + (long)cx * (IH * IW)) = v;
         }

@@ -76,6 +76,51 @@ def test_conv3_dgrad_overlap_add(B):
     assert torch.equal(dxg, dxg2), 'run-to-run deterministic'
 
 
+@pytest.mark.parametrize('B,u8,use_idx', [(1, False, False), (3, True, False), (37, False, True), (80, True, True),
+                                          (1024, False, True), (1031, True, False)])
+def test_conv1_gate_bits_conv2_dgrad(B, u8, use_idx):
+    """The ReLU gate of the first layer as bits (acktr_conv2d_fwd_gate_f32 / acktr_conv1_fwd_u8_gate) read by the second
+    layer's input gradient (flags bit 2): same y, mask == (y > 0) bit for bit, dx BIT-IDENTICAL to the float gate
+    (the reference keeps the activation itself for ReLU's backward, model.py:177)."""
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(4000 + B)
+    src = B + 3 if use_idx else B
+    x = torch.randint(0, 256, (src, 4, 84, 84), generator=g, dtype=torch.int32)
+    x = (x.to(torch.uint8) if u8 else x.float()).cuda()
+    idx = torch.randperm(src, generator=g)[:B].cuda() if use_idx else None
+    w1 = (torch.randn(32, 4, 8, 8, generator=g) * 0.05).cuda()
+    b1 = (torch.randn(32, generator=g) * 0.1).cuda()
+    w2 = (torch.randn(64, 32, 4, 4, generator=g) / np.sqrt(512.0)).cuda()
+    L1 = [('f1', w1, 4, 84, False), ('d2', w2, 2, 20, True)]
+    pk = ops.pack_conv_weights(L1, B, {})
+    assert pk and pk.get('f1') is not None and pk.get('d2') is not None
+    y0 = ops.conv2d_fwd(x, w1, b1, 4, in_scale=1.0 / 255.0, relu=True, gather_idx=idx, packed=pk['f1'])
+    gm = ops.gate_mask_like(B, 32, 20, 20, x.device)
+    gm.fill_(-1)                                            # stale contents must not survive
+    y1 = ops.conv2d_fwd(x, w1, b1, 4, in_scale=1.0 / 255.0, relu=True, gather_idx=idx, packed=pk['f1'], gate_mask=gm)
+    assert torch.equal(y0, y1)
+    # mask layout: word [r / 32][oc], bit r % 32, r = b*400 + pixel
+    R = B * 400
+    nt = (R + 31) // 32
+    bits = (y1 > 0).permute(0, 2, 3, 1).reshape(R, 32)      # [r][oc]
+    bits = torch.cat([bits, torch.zeros(nt * 32 - R, 32, dtype=torch.bool, device=bits.device)]).view(nt, 32, 32)
+    weights = (1 << torch.arange(32, dtype=torch.int64, device=bits.device)).view(1, 32, 1)
+    words = (bits.long() * weights).sum(1)                  # [tile][oc]
+    words = torch.where(words >= 2 ** 31, words - 2 ** 32, words).to(torch.int32)
+    assert torch.equal(gm.view(nt, 32), words)
+    dy = torch.randn(B, 64, 9, 9, generator=g).cuda()
+    dx_f = ops.conv2d_dgrad(dy, w2, y1, 2, packed=pk['d2'])
+    dx_b = ops.conv2d_dgrad(dy, w2, None, 2, packed=pk['d2'], gate_bits=gm)
+    assert torch.equal(dx_f.view(torch.int32), dx_b.view(torch.int32))
+    assert float(dx_f.abs().sum()) > 0
+    # shapes off those two paths reject the mask instead of ignoring it
+    with pytest.raises(RuntimeError, match='gate'):
+        ops.conv2d_fwd(y1, w2, None, 2, gate_mask=gm)
+    w3 = torch.randn(64, 64, 3, 3, generator=g).cuda()
+    with pytest.raises(RuntimeError, match='gate'):
+        ops.conv2d_dgrad(torch.randn(B, 64, 7, 7, device='cuda'), w3, None, 1, gate_bits=gm)
+
+
 def test_conv1_gather_fused():
     from a2c_ppo_acktr import ops
     g = torch.Generator().manual_seed(11)

@@ -298,15 +298,18 @@ int sw_num_cus() {
 #define ACKTR_NL_D2 8
 #endif
 using SwF1 = SwGeom<8, 8, 4, 84, 84, 4, 1, 1, ACKTR_NL_F1, HM_KX, 512, false>;
-using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, ACKTR_NL_F2, HM_KY, 512>;
+#ifndef ACKTR_KS_F2
+#define ACKTR_KS_F2 4      // (0: no K split of the odd tail item; comparison builds)
+#endif
+using SwF2 = SwGeom<4, 4, 2, 20, 20, 32, 2, 1, ACKTR_NL_F2, HM_KY, 512, true, ACKTR_KS_F2>;
 using SwF3 = SwGeom<3, 3, 1, 9, 9, 64, 1, 1, ACKTR_NL_F3, HM_CH, 512>;
 using SwD3 = SwGeom<3, 3, 1, 11, 11, 32, 2, 1, 8, HM_CH, 768>;     // padded 7x7 dY, flipped 3x3 kernel (stages of 8: room for the prefetched gate in 168 registers)
 using SwD2 = SwGeom<2, 2, 1, 11, 11, 64, 4, 2, ACKTR_NL_D2, HM_CH, 512>;     // padded 9x9 dY, four 2x2 phase kernels stacked along M
 
 static long sw_fwd_image_bytes(int geom, int C, int OC) {
-    if (geom == GEOM_8S4 && SwF1::ok(C, OC)) return SwF1::lds_bytes();
-    if (geom == GEOM_4S2 && SwF2::ok(C, OC)) return SwF2::lds_bytes();
-    if (geom == GEOM_3S1 && SwF3::ok(C, OC)) return SwF3::lds_bytes();
+    if (geom == GEOM_8S4 && SwF1::ok(C, OC)) return SwF1::image_floats() * 4;
+    if (geom == GEOM_4S2 && SwF2::ok(C, OC)) return SwF2::image_floats() * 4;
+    if (geom == GEOM_3S1 && SwF3::ok(C, OC)) return SwF3::image_floats() * 4;
     return 0;
 }
 // dgrad through the stationary kernel: C = channels of dX, OC = channels of dY (the reduction)
@@ -515,7 +518,7 @@ static int conv1_fwd_u8_impl(const uint8_t* x, const int64_t* gather_idx, const 
     ACKTR_ARG(B > 0 && (long)B * 32 * 400 < (1L << 31), "conv1_fwd_u8: bad batch size %d", B);
     ACKTR_ARG(((uintptr_t)x & 3) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)workspace & 15) == 0,
               "conv1_fwd_u8: x must be 4-byte, w and workspace 16-byte aligned");
-    ACKTR_ARG(workspace_bytes >= SwF1::lds_bytes(), "conv1_fwd_u8: workspace too small");
+    ACKTR_ARG(workspace_bytes >= SwF1::image_floats() * 4, "conv1_fwd_u8: workspace too small");
     hipStream_t s = (hipStream_t)stream;
     float* img = (float*)workspace;
     if (!prepacked) { const int rc = launch_sw_pack<SwF1>(w, img, 32, 0, 0, 0, s); if (rc) return rc; }

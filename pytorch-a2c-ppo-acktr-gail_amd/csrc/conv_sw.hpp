@@ -49,9 +49,13 @@ enum { HM_CH = 0, HM_KX = 1, HM_KY = 2 };
 // TM_ 32-row M blocks are resident in LDS; one work item (a wave's unit of work) is a 32-position tile times
 // TMW_ of them.  TMW_ < TM_ re-reads the activations TM_/TMW_ times (from L1/L2) but makes the items small
 // enough to balance: at minibatch 1024 there are only 1.3 - 1.6 full tiles per wave.
+// KSPLIT_ (0 or 4): a workgroup whose share of the last, partial round is ONE item more than a multiple of four -- a second
+// tail item for one of its four SIMDs while three waves of the workgroup have none -- cuts that item's reduction into four
+// parts, one per SIMD, and sums them through LDS in a fixed order (see conv_sw_kernel).
 template <int KH_, int KW_, int S_, int H_, int W_, int CH_, int TM_, int TMW_, int NL_, int HM_, int NT_ = 512,
-          bool BY_WG_ = true>
+          bool BY_WG_ = true, int KSPLIT_ = 0>
 struct SwGeom {
+    static constexpr int KSPLIT = KSPLIT_;
     // BY_WG: the waves of a workgroup take CONSECUTIVE work items (neighbouring tiles of the same images and both M
     // groups of a tile share the CU's L1 and the XCD's L2) instead of items a whole grid apart
     static constexpr bool BY_WG = BY_WG_;
@@ -94,7 +98,19 @@ struct SwGeom {
     static_assert(IMAGE_FLOATS * 4 <= 160 * 1024, "weights must fit in LDS");
     static bool ok(int C, int M) { return C == CH && M <= TM * 32; }
     __host__ __device__ static constexpr long image_floats() { return IMAGE_FLOATS; }
-    static constexpr long lds_bytes() { return IMAGE_FLOATS * 4; }
+    // K split: the parts' chunk pairs [q J/4, (q+1) J/4) must be the first part's, shifted by a constant offset
+    __host__ __device__ static constexpr bool ksplit_shift_ok() {
+        if (KSPLIT == 0) return true;
+        for (int q = 0; q < KSPLIT; ++q)
+            for (int i = 0; i < J / KSPLIT; ++i)
+                if (off0(q * (J / KSPLIT) + i) != off0(q * (J / KSPLIT)) + off0(i)) return false;
+        return true;
+    }
+    static_assert(KSPLIT == 0 || (KSPLIT == 4 && NT_ == 512 && J % (4 * KSPLIT) == 0 && NS % (2 * KSPLIT) == 0),
+                  "K split: four parts over the waves of a SIMD row, each an even number of stages and whole ring turns");
+    static constexpr long KS_SCRATCH_FLOATS = KSPLIT ? (long)(KSPLIT - 1) * TMW_ * 16 * 64 : 0;   // the helpers' partial tiles
+    static_assert((IMAGE_FLOATS + KS_SCRATCH_FLOATS) * 4 <= 160 * 1024, "weights + K-split scratch must fit in LDS");
+    static constexpr long lds_bytes() { return (IMAGE_FLOATS + KS_SCRATCH_FLOATS) * 4; }
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -486,9 +502,42 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
     const int slot = G::BY_WG ? blockIdx.x * G::NWAVES + wave : bx + gmain * wave;
     const int full = nitems / item_stride, rem = nitems - full * item_stride;
     const int tail_slot = wave * gmain + blockIdx.x;
-    const int my_items = full + (tail_slot < rem ? 1 : 0);
-    if (my_items == 0) return;
-    auto item_of = [&](int k) { return k < full ? k * item_stride + slot : full * item_stride + tail_slot; };
+    int my_items = full + (tail_slot < rem ? 1 : 0);
+    // K split (SwGeom::KSPLIT): this workgroup's tail items sit on its waves 0 .. tb-1.  With tb = 4 m + 1 the last of them
+    // would be a SECOND tail item for its SIMD while waves tb .. 4 m + 3 have none: those four waves (one per SIMD) take a
+    // quarter of its reduction each; the helpers leave their partial tiles in LDS and the item's own wave adds them in
+    // the order 1, 2, 3 and runs the epilogue.  (conv2 forward at minibatch 1024: 5184 items on 1024 SIMDs, five
+    // per SIMD and a sixth on 64 of them -- 65.2 us stand-alone against 56.7 at 1011 images.)
+    constexpr int KS = G::KSPLIT;
+    static_assert(!KS || (!RC && G::ksplit_shift_ok()), "K split: constant shift between the parts; not with row classes");
+    bool ks_wg = false;                                     // workgroup-uniform
+    int ks_part = -1, ks_item = 0;                          // this wave's part of the split item, or -1
+    if constexpr (KS != 0) {
+        const int tb = rem > (int)blockIdx.x ? (rem - (int)blockIdx.x + gmain - 1) / gmain : 0;
+        ks_wg = (tb & 3) == 1;
+        if (ks_wg && wave >= tb - 1 && wave < tb + 3) {
+            ks_part = wave - (tb - 1);
+            ks_item = full * item_stride + (tb - 1) * gmain + blockIdx.x;
+            my_items = full + 1;
+        }
+    }
+    if (my_items == 0) {
+        if (ks_wg) __syncthreads();                         // (the workgroup meets once behind the split item)
+        return;
+    }
+    auto item_of = [&](int k) {
+        return k < full ? k * item_stride + slot : (ks_part >= 0 ? ks_item : full * item_stride + tail_slot);
+    };
+    // the split item is the wave's last: a quarter of the stages, from the part's chunk pairs on
+    auto ks_adjust = [&](int k, const XT*& bs, int& nst_, int& woff_) {
+        if constexpr (KS != 0) {
+            if (ks_part >= 0 && k == my_items - 1) {
+                bs += G::off0(ks_part * (G::J / KS));
+                nst_ = NS / KS;
+                woff_ = ks_part * (G::J / KS) * TM * 64 * G::EP;
+            }
+        }
+    };
     int kround = 0;
     int item = item_of(0);
 
@@ -496,13 +545,15 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
     int r; bool valid;
     int mg = item % MG, nst, woff;
     const XT* base = lane_base(item / MG, r, valid, nst, woff);
+    ks_adjust(0, base, nst, woff);
     const float* la = lds_lane + mg * (TMW * 64 * G::EP) + woff;
     stage_load(buf[0], base, 0);
     load_a(0, la);
     load_a(1, la);
 
+    f32x16 acc[TMW];
+    typename Epi::template Pre<TMW> pre;
     while (true) {
-        f32x16 acc[TMW];
 #pragma unroll
         for (int a = 0; a < TMW; ++a)
 #pragma unroll
@@ -514,10 +565,12 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
         const XT* base_next = base;
         const int mg_next = has_next ? next_item % MG : mg;
         int nst_next = nst, woff_next = woff;
-        if (has_next) base_next = lane_base(next_item / MG, r_next, valid_next, nst_next, woff_next);
+        if (has_next) {
+            base_next = lane_base(next_item / MG, r_next, valid_next, nst_next, woff_next);
+            ks_adjust(kround + 1, base_next, nst_next, woff_next);
+        }
         const float* la_next = lds_lane + mg_next * (TMW * 64 * G::EP) + woff_next;
 
-        typename Epi::template Pre<TMW> pre;
         // one item: NST stages of NL chunk pairs (row classes: NS / 2 for the edge rows)
         auto run = [&](auto nst_c) {
             constexpr int NST = decltype(nst_c)::value, JN = NST * NL;
@@ -550,13 +603,38 @@ __global__ __launch_bounds__(G::NT) void conv_sw_kernel(const XT* __restrict__ x
         if constexpr (RC) {
             if (nst == NS) run(std::integral_constant<int, NS>{});
             else run(std::integral_constant<int, NS / 2>{});
+        } else if constexpr (KS != 0) {
+            if (nst == NS) run(std::integral_constant<int, NS>{});
+            else run(std::integral_constant<int, NS / (KS ? KS : 1)>{});
         } else {
             run(std::integral_constant<int, NS>{});
         }
+        if (!has_next && ks_part >= 0) break;               // a part of the split item: finished below
         epi.template store<TMW>(r, valid, h, mg, acc, pre);
         if (!has_next) break;
         item = next_item; base = base_next; r = r_next; valid = valid_next; mg = mg_next; nst = nst_next; woff = woff_next;
         la = la_next; ++kround;
+    }
+    if constexpr (KS != 0) {
+        if (ks_wg) {
+            float* sc = sw_smem + G::image_floats();         // [part - 1][a][g][lane]
+            if (ks_part > 0) {
+#pragma unroll
+                for (int a = 0; a < TMW; ++a)
+#pragma unroll
+                    for (int g = 0; g < 16; ++g) sc[(((ks_part - 1) * TMW + a) * 16 + g) * 64 + lane] = acc[a][g];
+            }
+            __syncthreads();
+            if (ks_part == 0) {
+#pragma unroll
+                for (int q = 0; q < KS - 1; ++q)
+#pragma unroll
+                    for (int a = 0; a < TMW; ++a)
+#pragma unroll
+                        for (int g = 0; g < 16; ++g) acc[a][g] += sc[((q * TMW + a) * 16 + g) * 64 + lane];
+                epi.template store<TMW>(r, valid, h, mg, acc, pre);
+            }
+        }
     }
 }
 

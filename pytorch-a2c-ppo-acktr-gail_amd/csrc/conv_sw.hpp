@@ -20,6 +20,8 @@
 // dY with (KH/S x KW/S) sub-kernels; the S*S phases share the position operand and are stacked along M, so a
 // lane ends up holding horizontally adjacent dX pixels and stores them as one 8-byte write.
 #pragma once
+#include <utility>
+
 #include "gemm_core.hpp"
 #include "head_finalize.hpp"
 
@@ -173,6 +175,17 @@ __global__ __launch_bounds__(256) void sw_pad_kernel(const float* __restrict__ d
 // ---------------------------------------------------------------------------------------------------
 // epilogues: lane = position r (valid or not), half h, acc[a][reg] -> row m = 32a + (reg&3) + 8(reg>>2) + 4h
 // ---------------------------------------------------------------------------------------------------
+// lane LANE of `old` := the wave-uniform value `val` (v_writelane_b32: scalar source, immediate lane select)
+template <int LANE>
+__device__ __forceinline__ int sw_writelane(int val, int old) {
+    asm("v_writelane_b32 %0, %1, %2" : "+v"(old) : "s"(val), "n"(LANE));
+    return old;
+}
+template <class F, int... I>
+__device__ __forceinline__ void sw_static_for(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+
 template <int SP, bool BIASED>
 struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
     float* y; const float* bias; int M; float scale; int relu;
@@ -199,34 +212,39 @@ struct SwFwdEpi {       // Y[b, m, sp] = relu?(acc*scale + bias[m])
         const bool full = (M % 32 == 0);                  // wave-uniform: no per-row bound checks
         const int m0 = 32 * TM * mg;
         if (m0 >= M) return;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-#pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
-                float v = acc[a][g] * scale;
-                if constexpr (BIASED) v += p.bv[a][g];
-                if (relu) v = v > 0.f ? v : 0.f;
-                if (valid && (full || m < M)) y[off + (long)m * SP] = v;
-            }
-        }
-        if (gmask) {        // (wave-uniform; every lane of the wave is here: r = 32*tile + li, so r >> 5 is the tile)
-            const int li = threadIdx.x & 31;
+        // GM: also the gate bits.  Every lane of the wave is here and r = 32*tile + li, so r >> 5 is the tile.  The ballot of
+        // row g (a scalar pair: low word = the h = 0 lanes' row, high word = the h = 1 lanes') goes into lane g of each
+        // half with v_writelane, so that after the sixteen rows lanes 0..15 / 32..47 hold the 32 words of the tile: ONE
+        // store into one 128-byte line.  (First version: sixteen 4-byte stores of two lanes each, +5 us on the conv1 forward;
+        // second: values recomputed in a loop of their own and a compare + select per row, +2.2 us.)
+        auto body = [&](auto gm_c) {
+            constexpr bool GM = decltype(gm_c)::value;
+            const unsigned long long vmask = GM ? __ballot(valid) : 0ull;
 #pragma unroll
             for (int a = 0; a < TM; ++a) {
-                unsigned word = 0;                             // lane li < 16 ends up with the word of ITS row g = li
-#pragma unroll
-                for (int g = 0; g < 16; ++g) {
+                int word = 0;
+                sw_static_for([&](auto gc) {
+                    constexpr int g = decltype(gc)::value;
+                    const int m = m0 + 32 * a + (g & 3) + 8 * (g >> 2) + 4 * h;
                     float v = acc[a][g] * scale;
                     if constexpr (BIASED) v += p.bv[a][g];
-                    const unsigned long long bal = __ballot(valid && v > 0.f);
-                    const unsigned mine = h ? (unsigned)(bal >> 32) : (unsigned)bal;
-                    word = li == g ? mine : word;
+                    if (relu) v = v > 0.f ? v : 0.f;
+                    if (valid && (full || m < M)) y[off + (long)m * SP] = v;
+                    if constexpr (GM) {
+                        const unsigned long long bal = __ballot(v > 0.f) & vmask;
+                        word = sw_writelane<g>((int)(unsigned)bal, word);
+                        word = sw_writelane<32 + g>((int)(unsigned)(bal >> 32), word);
+                    }
+                }, std::make_integer_sequence<int, 16>{});
+                if constexpr (GM) {
+                    const int li = threadIdx.x & 31;
+                    const int m = m0 + 32 * a + (li & 3) + 8 * (li >> 2) + 4 * h;
+                    if (li < 16 && (full || m < M)) gmask[(long)(r >> 5) * M + m] = (unsigned)word;
                 }
-                const int m = m0 + 32 * a + (li & 3) + 8 * (li >> 2) + 4 * h;
-                if (li < 16 && (full || m < M)) gmask[(long)(r >> 5) * M + m] = word;      // 32 words of one 128-byte line
             }
-        }
+        };
+        if (gmask) body(std::true_type{});
+        else body(std::false_type{});
     }
 };
 

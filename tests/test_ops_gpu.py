@@ -121,6 +121,24 @@ def test_conv1_gate_bits_conv2_dgrad(B, u8, use_idx):
         ops.conv2d_dgrad(torch.randn(B, 64, 7, 7, device='cuda'), w3, None, 1, gate_bits=gm)
 
 
+@pytest.mark.parametrize('B', [300, 1011, 1024])
+def test_conv2_fwd_k_split_tail(B):
+    """conv2's forward (model.py:177) where workgroups end with 4m + 1 tail items and cut the last one into four K parts
+    (SwGeom::KSPLIT, conv_sw.hpp): B = 1024 -> five tail items on 64 workgroups, B = 300 -> five on 16 and six on the rest,
+    B = 1011 -> none.  Against torch's CPU conv2d, and bit-identical run to run (the parts are summed in a fixed order)."""
+    from a2c_ppo_acktr import ops
+    g = torch.Generator().manual_seed(7000 + B)
+    x = torch.relu(torch.rand(B, 32, 20, 20, generator=g) - 0.3)
+    w = torch.randn(64, 32, 4, 4, generator=g) / np.sqrt(512.0)
+    b = torch.randn(64, generator=g) * 0.1
+    ref = F.relu(F.conv2d(x, w, b, stride=2))
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    y0 = ops.conv2d_fwd(xd, wd, bd, 2)
+    assert rel(y0, ref) < TOL
+    y1 = ops.conv2d_fwd(xd, wd, bd, 2)
+    assert torch.equal(y0.view(torch.int32), y1.view(torch.int32))
+
+
 def test_conv1_gather_fused():
     from a2c_ppo_acktr import ops
     g = torch.Generator().manual_seed(11)

@@ -270,9 +270,10 @@ def refresh_conv_images(policy, B):
     return ops.conv_image_map(layers, B, cache, lambda w: policy._offsets[id(w)][0])
 
 
-def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True, trust_images=False):
+def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True, trust_images=False, gate_bits=True):
     """head=False stops at the FC features (`head_step` then runs head, loss and their backward in one launch).
-    trust_images: see refresh_conv_images."""
+    trust_images: see refresh_conv_images.  gate_bits=False: a forward nobody differentiates (Policy.act / get_value)
+    skips the ReLU gate bits that conv2's input gradient would read."""
     inputs = inputs.contiguous()
     _check_input(policy, inputs, gather_idx)
     rec = policy.is_recurrent
@@ -289,7 +290,7 @@ def forward(policy, inputs, gather_idx=None, rnn_hxs=None, masks=None, head=True
         # conv2's input gradient needs only the sign of y1: the conv1 forward leaves it as bits (1.6 MB instead of a second
         # pass over 52 MB at 1024 frames) when both layers run their stationary-weight kernels
         a.g1 = ops.gate_mask_like(B, 32, 20, 20, inputs.device) \
-            if (GATE_BITS and pk.get('f1') is not None and pk.get('d2') is not None) else None
+            if (GATE_BITS and gate_bits and pk.get('f1') is not None and pk.get('d2') is not None) else None
         a.y1 = ops.conv2d_fwd(inputs, L['conv1'][0], L['conv1'][1].view(-1), 4, in_scale=1.0 / 255.0, relu=True,
                               gather_idx=gather_idx, packed=pk.get('f1'), gate_mask=a.g1)
         a.y2 = ops.conv2d_fwd(a.y1, L['conv2'][0], L['conv2'][1].view(-1), 2, packed=pk.get('f2'))

@@ -192,7 +192,7 @@ class Policy(nn.Module):
         normal [B, A] noise on the GPU generator instead: same distributions, no host draw or copy, another stream."""
         from . import _hip
         with torch.no_grad():
-            acts = engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks)
+            acts = engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks, gate_bits=False)
             dev = inputs.device
             B, A, kind = inputs.shape[0], self.dist.num_outputs, self.dist.kind
             noise, mode = None, 1
@@ -219,7 +219,7 @@ class Policy(nn.Module):
     def get_value(self, inputs, rnn_hxs, masks):
         """reference model.py:68-70."""
         with torch.no_grad():
-            return engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks).value().clone()
+            return engine.forward(self, inputs, rnn_hxs=rnn_hxs, masks=masks, gate_bits=False).value().clone()
 
     def evaluate_actions(self, inputs, rnn_hxs, masks, action):
         """reference model.py:72-79: (value [B,1], action_log_probs [B,1], dist_entropy scalar, rnn_hxs).
